@@ -1,0 +1,476 @@
+// Device-side data layout and rule kernels' building blocks (gfx950, wave64).
+//
+// One wavefront owns one game.  The eight most recent boards of the game
+// (current + 7 history) sit in LDS as a ring of int8 planes; lane l owns the
+// cells l, l+64, l+128, ... of every board.  Scalars of the state are
+// wave-uniform.  All functions here are called by every lane of the wave.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define AZ_CP 384   // bytes per board (cells padded)
+#define AZ_OP 384   // bytes per action mask
+#define AZ_NJ 6     // ceil(361 / 64)
+#define AZ_WAVE 64
+
+enum { G_GO = 0, G_REVERSI = 1, G_MNK = 2 };
+
+// int32 scalars of one game state, one 64-byte line per slot
+enum {
+    S_HEAD = 0, S_CUR, S_KO, S_TURNS, S_NHIST, S_LAST1, S_LAST2, S_END, S_WIN, S_WINSET,
+    S_PB, S_PW, S_PRB, S_PRW, S_STONES, S_PAD, S_N
+};
+
+// search machine phases of a slot
+enum { PH_IDLE = 0, PH_NEED_START = 1, PH_IN_SEARCH = 2, PH_SEARCH_DONE = 3, PH_GAME_DONE = 4 };
+
+#define NODE_ROOT (-1)
+#define NOMOVE (-2)
+
+enum {
+    C_STEPS = 0, C_EVALS, C_MOVES, C_GAMES, C_LEVELS, C_CHILDREN, C_EDGES, C_RULEMOVES, C_NLEAVES, C_N = 16
+};
+
+struct Geo {
+    int game, H, W, NC, O, k;
+};
+
+struct PS {  // wave-uniform scalars of a (playout) state
+    int head, cur, ko, turns, nhist, last1, last2, is_end, winner, winner_set;
+    int passes_b, passes_w, pris_b, pris_w, stones;
+};
+
+struct __align__(16) WLds {
+    int8_t ring[8][AZ_CP];
+    int16_t label[AZ_CP];
+    int32_t libs[AZ_CP];
+    uint8_t mask[AZ_OP];
+    int32_t tmp[64];
+    double cum[AZ_OP];
+};
+
+struct Dev {
+    Geo geo;
+    int G;
+    int max_playout, transform_on, transform_types, dirichlet_before, max_turn;
+    double d_alpha, d_epsilon;
+    int EC, BC, MAXD;
+    int rng_replay, record, traj_plies;
+    unsigned long long seed;
+    // state
+    int8_t *ring;        // [G][8][AZ_CP]
+    int32_t *sc;         // [G][S_N]
+    // machine
+    int32_t *phase, *side, *dflag, *pdone, *automode, *ply, *err;
+    // leaf of the current round
+    int32_t *leaf_valid, *leaf_node, *leaf_block, *leaf_player, *leaf_end, *leaf_winner, *leaf_tid, *leaf_root, *path_len;
+    int32_t *path_node;  // [G][MAXD]
+    int8_t *path_player; // [G][MAXD]
+    uint8_t *leaf_mask;  // [G][AZ_OP]
+    int8_t *planes;      // [G][17][NC]
+    float *priors;       // [G][O]
+    float *values;       // [G]
+    // trees [2G]
+    int32_t *rootN; float *rootW; float *rootP; int32_t *rootBlock; int32_t *nBlocks; int32_t *nEdges;
+    int32_t *eN; float *eW; float *eP; int32_t *eChild; int16_t *eAct;       // [2G][EC]
+    int32_t *bStart, *bCount, *bOwner, *bParent, *bMap, *bShift;             // [2G][BC]
+    int32_t *pending;    // [2G] move to re-root with, NOMOVE = none
+    // rng
+    const int32_t **rt; long long *rt_n, *rt_i;
+    const double **re; long long *re_n, *re_i;
+    const double **ru; long long *ru_n, *ru_i;
+    unsigned long long *rng_ctr;  // [G]
+    // trajectories
+    int16_t *tr_moves;   // [G][traj_plies]
+    int32_t *tr_visits;  // [G][traj_plies][O]
+    int32_t *tr_winner;  // [G]
+    // counters
+    unsigned long long *ctr;
+};
+
+#define WSYNC() __syncthreads()
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ int8_t *cur_board(WLds &L, const PS &s) { return L.ring[s.head & 7]; }
+// board_history[t], t = 0 (oldest) .. 6 (newest); t = 7 is the current board
+__device__ __forceinline__ int8_t *hist_board(WLds &L, const PS &s, int t) { return L.ring[(s.head + 1 + t) & 7]; }
+
+__device__ __forceinline__ void load_scalars(const Dev &D, int g, PS &s)
+{
+    const int32_t *sc = D.sc + (size_t)g * S_N;
+    s.head = sc[S_HEAD]; s.cur = sc[S_CUR]; s.ko = sc[S_KO]; s.turns = sc[S_TURNS];
+    s.nhist = sc[S_NHIST]; s.last1 = sc[S_LAST1]; s.last2 = sc[S_LAST2]; s.is_end = sc[S_END];
+    s.winner = sc[S_WIN]; s.winner_set = sc[S_WINSET]; s.passes_b = sc[S_PB]; s.passes_w = sc[S_PW];
+    s.pris_b = sc[S_PRB]; s.pris_w = sc[S_PRW]; s.stones = sc[S_STONES];
+}
+
+__device__ __forceinline__ void store_scalars(const Dev &D, int g, const PS &s)
+{
+    if (lane_id() == 0) {
+        int32_t *sc = D.sc + (size_t)g * S_N;
+        sc[S_HEAD] = s.head; sc[S_CUR] = s.cur; sc[S_KO] = s.ko; sc[S_TURNS] = s.turns;
+        sc[S_NHIST] = s.nhist; sc[S_LAST1] = s.last1; sc[S_LAST2] = s.last2; sc[S_END] = s.is_end;
+        sc[S_WIN] = s.winner; sc[S_WINSET] = s.winner_set; sc[S_PB] = s.passes_b; sc[S_PW] = s.passes_w;
+        sc[S_PRB] = s.pris_b; sc[S_PRW] = s.pris_w; sc[S_STONES] = s.stones;
+    }
+}
+
+// whole ring (3 KiB) <-> LDS, 16 bytes per lane per trip
+__device__ __forceinline__ void load_ring(const Dev &D, int g, WLds &L)
+{
+    const int4 *src = reinterpret_cast<const int4 *>(D.ring + (size_t)g * 8 * AZ_CP);
+    int4 *dst = reinterpret_cast<int4 *>(&L.ring[0][0]);
+    for (int q = lane_id(); q < 8 * AZ_CP / 16; q += AZ_WAVE) dst[q] = src[q];
+    WSYNC();
+}
+
+__device__ __forceinline__ void store_ring(const Dev &D, int g, WLds &L)
+{
+    WSYNC();
+    int4 *dst = reinterpret_cast<int4 *>(D.ring + (size_t)g * 8 * AZ_CP);
+    const int4 *src = reinterpret_cast<const int4 *>(&L.ring[0][0]);
+    for (int q = lane_id(); q < 8 * AZ_CP / 16; q += AZ_WAVE) dst[q] = src[q];
+}
+
+// board_history.append(board.copy()); board_history.pop(0)
+__device__ __forceinline__ void push_history(WLds &L, PS &s)
+{
+    const int8_t *b = cur_board(L, s);
+    int nh = (s.head + 1) & 7;
+    int8_t *d = L.ring[nh];
+    const int *b4 = reinterpret_cast<const int *>(b);
+    int *d4 = reinterpret_cast<int *>(d);
+    for (int q = lane_id(); q < AZ_CP / 4; q += AZ_WAVE) d4[q] = b4[q];
+    s.head = nh;
+    WSYNC();
+}
+
+__device__ __forceinline__ void append_move(PS &s, int a)
+{
+    s.last2 = s.last1;
+    s.last1 = a;
+    s.nhist++;
+}
+
+// ---------------------------------------------------------------------------
+// Go: chain labels (min cell index of the chain) and liberty counts
+// ---------------------------------------------------------------------------
+
+__device__ void go_label(const Geo &G, WLds &L, const int8_t *b)
+{
+    const int lane = lane_id();
+    const int W = G.W, H = G.H, NC = G.NC;
+    for (int i = lane; i < NC; i += AZ_WAVE) {
+        L.label[i] = (int16_t)i;
+        L.libs[i] = 0;
+    }
+    WSYNC();
+    for (;;) {
+        int changed = 0;
+        for (int i = lane; i < NC; i += AZ_WAVE) {
+            int c = b[i];
+            if (c == 0) continue;
+            int x = i / W, y = i - x * W;
+            int m = L.label[i], m0 = m;
+            if (x > 0 && b[i - W] == c) m = min(m, (int)L.label[i - W]);
+            if (x + 1 < H && b[i + W] == c) m = min(m, (int)L.label[i + W]);
+            if (y > 0 && b[i - 1] == c) m = min(m, (int)L.label[i - 1]);
+            if (y + 1 < W && b[i + 1] == c) m = min(m, (int)L.label[i + 1]);
+            m = min(m, (int)L.label[m]);
+            if (m < m0) { L.label[i] = (int16_t)m; changed = 1; }
+        }
+        WSYNC();
+        if (!__any(changed)) break;
+    }
+    // liberties: every empty point adds one to each distinct neighbouring chain
+    for (int i = lane; i < NC; i += AZ_WAVE) {
+        if (b[i] != 0) continue;
+        int x = i / W, y = i - x * W;
+        int l0 = -1, l1 = -1, l2 = -1, l3 = -1;
+        if (x > 0 && b[i - W] != 0) l0 = L.label[i - W];
+        if (x + 1 < H && b[i + W] != 0) l1 = L.label[i + W];
+        if (y > 0 && b[i - 1] != 0) l2 = L.label[i - 1];
+        if (y + 1 < W && b[i + 1] != 0) l3 = L.label[i + 1];
+        if (l0 >= 0) atomicAdd(&L.libs[l0], 1);
+        if (l1 >= 0 && l1 != l0) atomicAdd(&L.libs[l1], 1);
+        if (l2 >= 0 && l2 != l0 && l2 != l1) atomicAdd(&L.libs[l2], 1);
+        if (l3 >= 0 && l3 != l0 && l3 != l1 && l3 != l2) atomicAdd(&L.libs[l3], 1);
+    }
+    WSYNC();
+}
+
+__device__ __forceinline__ int go_chain_libs(WLds &L, int cell) { return L.libs[L.label[cell]]; }
+
+// ---------------------------------------------------------------------------
+// legal mask -> L.mask[0..O), returns number of legal actions
+// ---------------------------------------------------------------------------
+
+__device__ int dev_legal_mask(const Geo &G, WLds &L, const PS &s)
+{
+    const int lane = lane_id();
+    const int W = G.W, H = G.H, NC = G.NC;
+    const int8_t *b = cur_board(L, s);
+    int count = 0;
+    if (G.game == G_GO) {
+        go_label(G, L, b);
+        for (int i0 = 0; i0 < NC; i0 += AZ_WAVE) {
+            int i = i0 + lane;
+            int legal = 0;
+            if (i < NC && b[i] == 0) {
+                int x = i / W, y = i - x * W;
+                int nb[4], n = 0;
+                if (x > 0) nb[n++] = i - W;
+                if (x + 1 < H) nb[n++] = i + W;
+                if (y > 0) nb[n++] = i - 1;
+                if (y + 1 < W) nb[n++] = i + 1;
+                for (int q = 0; q < n; q++) {
+                    int r = nb[q], c = b[r];
+                    if (c == 0) legal = 1;
+                    else {
+                        int lb = go_chain_libs(L, r);
+                        if (c == s.cur && lb >= 2) legal = 1;
+                        if (c == -s.cur && lb == 1) legal = 1;
+                    }
+                }
+                if (i == s.ko) legal = 0;
+            }
+            if (i < NC) L.mask[i] = (uint8_t)legal;
+            count += __popcll(__ballot(legal));
+        }
+        if (lane == 0) L.mask[NC] = 1;  // passing is always legal
+        count += 1;
+    } else if (G.game == G_REVERSI) {
+        for (int i0 = 0; i0 < NC; i0 += AZ_WAVE) {
+            int i = i0 + lane;
+            int legal = 0;
+            if (i < NC && b[i] == 0) {
+                int x0 = i / W, y0 = i - x0 * W;
+                for (int d = 0; d < 9 && !legal; d++) {
+                    int dx = d / 3 - 1, dy = d % 3 - 1;
+                    if (dx == 0 && dy == 0) continue;
+                    int x = x0 + dx, y = y0 + dy, run = 0;
+                    while (x >= 0 && y >= 0 && x < H && y < W && b[x * W + y] == -s.cur) { x += dx; y += dy; run++; }
+                    if (run > 0 && x >= 0 && y >= 0 && x < H && y < W && b[x * W + y] == s.cur) legal = 1;
+                }
+            }
+            if (i < NC) L.mask[i] = (uint8_t)legal;
+            count += __popcll(__ballot(legal));
+        }
+        // PASS is legal only when no placement is
+        if (lane == 0) L.mask[NC] = (uint8_t)(count == 0);
+        if (count == 0) count = 1;
+    } else {
+        for (int i0 = 0; i0 < NC; i0 += AZ_WAVE) {
+            int i = i0 + lane;
+            int legal = (i < NC && b[i] == 0);
+            if (i < NC) L.mask[i] = (uint8_t)legal;
+            count += __popcll(__ballot(legal));
+        }
+    }
+    WSYNC();
+    return count;
+}
+
+// ---------------------------------------------------------------------------
+// do_move for a move already known to be legal
+// ---------------------------------------------------------------------------
+
+__device__ void dev_do_move(const Geo &G, WLds &L, PS &s, int a)
+{
+    const int lane = lane_id();
+    const int W = G.W, H = G.H, NC = G.NC;
+    const int color = s.cur;
+    if (G.game == G_GO) {
+        s.ko = -1;
+        push_history(L, s);
+        int8_t *b = cur_board(L, s);
+        if (a != NC) {
+            if (lane == 0) b[a] = (int8_t)color;
+            WSYNC();
+            go_label(G, L, b);
+            // ko bookkeeping needs the pre-capture neighbourhood of `a`
+            int x = a / W, y = a - x * W;
+            int nb[4], n = 0;
+            if (x > 0) nb[n++] = a - W;
+            if (x + 1 < H) nb[n++] = a + W;
+            if (y > 0) nb[n++] = a - 1;
+            if (y + 1 < W) nb[n++] = a + 1;
+            int friendly = 0, empty = 0, first = -1;
+            for (int q = 0; q < n; q++) {
+                int r = nb[q], c = b[r];
+                if (c == color) friendly = 1;
+                else if (c == 0) empty = 1;
+                else if (first < 0 && go_chain_libs(L, r) == 0) first = r;
+            }
+            int ko = -1;
+            if (first >= 0 && !friendly && !empty) {
+                // captured chain is a single stone iff it has no same-colour neighbour
+                int fx = first / W, fy = first - fx * W, single = 1;
+                if (fx > 0 && b[first - W] == -color) single = 0;
+                if (fx + 1 < H && b[first + W] == -color) single = 0;
+                if (fy > 0 && b[first - 1] == -color) single = 0;
+                if (fy + 1 < W && b[first + 1] == -color) single = 0;
+                if (single) ko = first;
+            }
+            // remove every opposing chain left without liberties
+            int removed = 0;
+            int rem[AZ_NJ];
+#pragma unroll
+            for (int j = 0; j < AZ_NJ; j++) {
+                int i = lane + j * AZ_WAVE;
+                rem[j] = (i < NC && b[i] == -color && go_chain_libs(L, i) == 0);
+                removed += __popcll(__ballot(rem[j]));
+            }
+            WSYNC();
+#pragma unroll
+            for (int j = 0; j < AZ_NJ; j++) {
+                int i = lane + j * AZ_WAVE;
+                if (rem[j]) b[i] = 0;
+            }
+            WSYNC();
+            if (color == 1) s.pris_w += removed; else s.pris_b += removed;
+            s.ko = ko;
+        } else {
+            if (color == 1) s.passes_b++; else s.passes_w++;
+        }
+        s.cur = -color;
+        append_move(s, a);
+        s.turns++;
+        if (s.nhist > 1 && s.last1 == NC && s.last2 == NC && s.cur == -1) s.is_end = 1;
+    } else if (G.game == G_REVERSI) {
+        push_history(L, s);
+        int8_t *b = cur_board(L, s);
+        append_move(s, a);
+        s.turns++;
+        if (a != NC) {
+            if (lane == 0) b[a] = (int8_t)color;
+            WSYNC();
+            s.stones++;
+            int x0 = a / W, y0 = a - x0 * W;
+            if (lane < 9 && lane != 4) {
+                int dx = lane / 3 - 1, dy = lane % 3 - 1;
+                int x = x0 + dx, y = y0 + dy, run = 0;
+                while (x >= 0 && y >= 0 && x < H && y < W && b[x * W + y] == -color) { x += dx; y += dy; run++; }
+                if (run > 0 && x >= 0 && y >= 0 && x < H && y < W && b[x * W + y] == color) {
+                    for (int q = 0; q < run; q++) { x -= dx; y -= dy; b[x * W + y] = (int8_t)color; }
+                }
+            }
+            WSYNC();
+            if (s.stones == NC) s.is_end = 1;
+        } else {
+            if (s.nhist >= 2 && s.last2 == NC) s.is_end = 1;
+        }
+        s.cur = -color;
+    } else {
+        push_history(L, s);
+        int8_t *b = cur_board(L, s);
+        append_move(s, a);
+        if (lane == 0) b[a] = (int8_t)color;
+        WSYNC();
+        s.turns++;
+        int x0 = a / W, y0 = a - x0 * W;
+        if (lane < 8) {
+            const int dxs[8] = {1, -1, 0, 0, 1, -1, 1, -1};
+            const int dys[8] = {0, 0, 1, -1, 1, -1, -1, 1};
+            int dx = dxs[lane], dy = dys[lane];
+            int x = x0 + dx, y = y0 + dy, run = 0;
+            while (x >= 0 && y >= 0 && x < H && y < W && b[x * W + y] == color) { x += dx; y += dy; run++; }
+            L.tmp[lane] = run;
+        }
+        WSYNC();
+        int hc = 1 + L.tmp[0] + L.tmp[1], vc = 1 + L.tmp[2] + L.tmp[3];
+        int d1 = 1 + L.tmp[4] + L.tmp[5], d2 = 1 + L.tmp[6] + L.tmp[7];
+        WSYNC();
+        if (hc >= G.k || vc >= G.k || d1 >= G.k || d2 >= G.k) { s.is_end = 1; s.winner = color; s.winner_set = 1; }
+        else if (s.turns == NC) { s.is_end = 1; s.winner = 0; s.winner_set = 1; }
+        s.cur = -color;
+    }
+}
+
+// get_winner(): +1 / -1 / 0 ; mnk before the end: 2 (None)
+__device__ int dev_winner(const Geo &G, WLds &L, const PS &s)
+{
+    const int lane = lane_id();
+    const int W = G.W, H = G.H, NC = G.NC;
+    const int8_t *b = cur_board(L, s);
+    if (G.game == G_MNK) return s.winner_set ? s.winner : 2;
+    int nb_ = 0, nw_ = 0;
+    for (int i0 = 0; i0 < NC; i0 += AZ_WAVE) {
+        int i = i0 + lane;
+        int isb = 0, isw = 0;
+        if (i < NC) {
+            int c = b[i];
+            if (c == 1) isb = 1;
+            else if (c == -1) isw = 1;
+            else if (G.game == G_GO) {
+                int x = i / W, y = i - x * W, allb = 1, allw = 1;
+                if (x > 0) { allb &= b[i - W] == 1; allw &= b[i - W] == -1; }
+                if (x + 1 < H) { allb &= b[i + W] == 1; allw &= b[i + W] == -1; }
+                if (y > 0) { allb &= b[i - 1] == 1; allw &= b[i - 1] == -1; }
+                if (y + 1 < W) { allb &= b[i + 1] == 1; allw &= b[i + 1] == -1; }
+                if (allb) isb = 1; else if (allw) isw = 1;
+            }
+        }
+        nb_ += __popcll(__ballot(isb));
+        nw_ += __popcll(__ballot(isw));
+    }
+    if (G.game == G_GO) {
+        // komi 7.5 and one point off per own pass, compared in half points
+        int sb2 = 2 * (nb_ - s.passes_b), sw2 = 2 * (nw_ - s.passes_w) + 15;
+        return sb2 > sw2 ? 1 : (sw2 > sb2 ? -1 : 0);
+    }
+    return nb_ > nw_ ? 1 : (nb_ < nw_ ? -1 : 0);
+}
+
+// source cell of transformed cell i (also: label of the i-th policy entry after
+// the reverse transform); square boards when tid != 0
+__device__ __forceinline__ int transform_src(int i, int H, int W, int tid)
+{
+    int x = i / W, y = i - x * W, nx, ny;
+    switch (tid & 3) {
+    case 1: nx = y; ny = W - 1 - x; break;
+    case 2: nx = H - 1 - x; ny = W - 1 - y; break;
+    case 3: nx = H - 1 - y; ny = x; break;
+    default: nx = x; ny = y; break;
+    }
+    if (tid >= 4) ny = W - 1 - ny;
+    return nx * W + ny;
+}
+
+// 17 int8 planes of the state as seen after transform(tid), NCHW
+__device__ void dev_features(const Geo &G, WLds &L, const PS &s, int tid, int8_t *out)
+{
+    const int lane = lane_id();
+    const int NC = G.NC;
+    for (int i0 = 0; i0 < NC; i0 += AZ_WAVE) {
+        int i = i0 + lane;
+        if (i >= NC) continue;
+        int src = tid ? transform_src(i, G.H, G.W, tid) : i;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            int c = hist_board(L, s, t)[src];
+            out[(2 * t) * NC + i] = (int8_t)(c == s.cur);
+            out[(2 * t + 1) * NC + i] = (int8_t)(c == -s.cur);
+        }
+        out[16 * NC + i] = (int8_t)(s.cur == 1);
+    }
+}

@@ -1,0 +1,760 @@
+// Host side of the C ABI declared in include/az_engine.h.
+#include "../../include/az_engine.h"
+#include "az_kernels.h"
+#include "az_tower.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static std::string g_create_error;
+
+#define HIPCHK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            h->error = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+            return AZ_ERR_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+struct az_engine {
+    az_config cfg;
+    Dev D;
+    hipStream_t stream = nullptr;
+    std::vector<void *> allocs;
+    std::string error;
+    Tower *tower = nullptr;
+    // staging
+    int32_t *st_a = nullptr, *st_b = nullptr, *st_c = nullptr, *st_d = nullptr, *st_e = nullptr;  // [max(G,64)] each
+    uint8_t *st_bytes = nullptr;   // [G * max(O, 17*NC)]
+    size_t st_bytes_n = 0;
+    // replay streams
+    std::vector<void *> rng_bufs;  // 3 per slot
+    // timing
+    hipEvent_t ev[4];
+    double tower_ms = 0, select_ms = 0, finish_ms = 0;
+    uint64_t tower_calls = 0, tower_evals = 0, steps = 0;
+    bool started = false;
+};
+
+template <typename T>
+static T *dalloc(az_engine *h, size_t n, bool zero = true)
+{
+    void *p = nullptr;
+    if (n == 0) n = 1;
+    if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
+    if (zero) hipMemset(p, 0, n * sizeof(T));
+    h->allocs.push_back(p);
+    return reinterpret_cast<T *>(p);
+}
+
+static int set_err(az_engine *h, int code, const char *msg)
+{
+    h->error = msg;
+    return code;
+}
+
+static const char *err_text(int code)
+{
+    switch (code) {
+    case AZ_ERR_TREE_FULL: return "tree arena full (raise tree_edge_cap / tree_block_cap)";
+    case AZ_ERR_RNG_UNDERFLOW: return "RNG replay stream underflow";
+    case AZ_ERR_DEPTH: return "playout deeper than max_depth";
+    case AZ_ERR_STATE: return "search finished without a legal move";
+    default: return "device-side error";
+    }
+}
+
+// copies the per-slot error words back and reports the first one
+static int check_slot_errors(az_engine *h)
+{
+    std::vector<int32_t> e(h->D.G);
+    HIPCHK(hipMemcpyAsync(e.data(), h->D.err, sizeof(int32_t) * h->D.G, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int g = 0; g < h->D.G; g++)
+        if (e[g] != 0) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "slot %d: %s", g, err_text(e[g]));
+            h->error = buf;
+            return e[g];
+        }
+    return AZ_OK;
+}
+
+extern "C" const char *az_last_error(az_engine *h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+extern "C" void az_engine_destroy(az_engine *h)
+{
+    if (!h) return;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->tower) tower_destroy(h->tower);
+    for (void *p : h->allocs) hipFree(p);
+    for (void *p : h->rng_bufs) if (p) hipFree(p);
+    for (int i = 0; i < 4; i++) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" az_engine *az_engine_create(const az_config *cfg)
+{
+    if (!cfg) { g_create_error = "null config"; return nullptr; }
+    const int H = cfg->board_height, W = cfg->board_width, NC = H * W;
+    if (cfg->game < 0 || cfg->game > 2 || H < 1 || W < 1 || NC > AZ_MAX_CELLS || cfg->n_slots < 1) {
+        g_create_error = "bad game / board size / n_slots";
+        return nullptr;
+    }
+    if (cfg->transform_types > 1 && H != W) {
+        g_create_error = "dihedral transforms need a square board (reference asserts this: env/mnk.py:199)";
+        return nullptr;
+    }
+    if (cfg->game == AZ_REVERSI && (H != W || (H & 1))) { g_create_error = "reversi needs an even square board"; return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_error = "no HIP device"; return nullptr; }
+    if (hipSetDevice(cfg->device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return nullptr; }
+    az_engine *h = new az_engine();
+    for (int i = 0; i < 4; i++) h->ev[i] = nullptr;
+    h->cfg = *cfg;
+    Dev &D = h->D;
+    memset(&D, 0, sizeof(D));
+    D.geo.game = cfg->game; D.geo.H = H; D.geo.W = W; D.geo.NC = NC; D.geo.k = cfg->k;
+    D.geo.O = NC + (cfg->game == AZ_MNK ? 0 : 1);
+    const int G = cfg->n_slots, O = D.geo.O;
+    D.G = G;
+    D.max_playout = cfg->max_playout;
+    D.transform_types = cfg->transform_types;
+    D.transform_on = !(cfg->transform_types == 0 || cfg->transform_types == 1);
+    D.dirichlet_before = cfg->dirichlet_before;
+    D.max_turn = cfg->max_turn;
+    D.d_alpha = cfg->d_alpha; D.d_epsilon = cfg->d_epsilon;
+    long long ec = cfg->tree_edge_cap > 0 ? cfg->tree_edge_cap : 3LL * (cfg->max_playout + 1) * O;
+    long long bc = cfg->tree_block_cap > 0 ? cfg->tree_block_cap : 8LL * (cfg->max_playout + 1);
+    if (ec < O) ec = O;
+    if (bc < 2) bc = 2;
+    if (ec > 0x7fffffffLL || bc > 0x7fffffffLL) { g_create_error = "tree caps too large"; delete h; return nullptr; }
+    D.EC = (int)ec; D.BC = (int)bc;
+    D.MAXD = cfg->max_depth > 0 ? cfg->max_depth : 1024;
+    D.rng_replay = cfg->rng_replay; D.seed = cfg->seed;
+    D.record = cfg->record_trajectories;
+    D.traj_plies = cfg->record_trajectories ? cfg->max_turn + 2 : 1;
+
+    bool ok = hipStreamCreate(&h->stream) == hipSuccess;
+    for (int i = 0; i < 4 && ok; i++) ok = hipEventCreate(&h->ev[i]) == hipSuccess;
+#define A(field, T, n) ok = ok && ((D.field = dalloc<T>(h, (size_t)(n))) != nullptr)
+    A(ring, int8_t, (size_t)G * 8 * AZ_CP);
+    A(sc, int32_t, (size_t)G * S_N);
+    A(phase, int32_t, G); A(side, int32_t, G); A(dflag, int32_t, G); A(pdone, int32_t, G);
+    A(automode, int32_t, G); A(ply, int32_t, G); A(err, int32_t, G);
+    A(leaf_valid, int32_t, G); A(leaf_node, int32_t, G); A(leaf_block, int32_t, G); A(leaf_player, int32_t, G);
+    A(leaf_end, int32_t, G); A(leaf_winner, int32_t, G); A(leaf_tid, int32_t, G); A(leaf_root, int32_t, G);
+    A(path_len, int32_t, G);
+    A(path_node, int32_t, (size_t)G * D.MAXD);
+    A(path_player, int8_t, (size_t)G * D.MAXD);
+    A(leaf_mask, uint8_t, (size_t)G * AZ_OP);
+    A(planes, int8_t, (size_t)G * 17 * NC + 64);
+    A(priors, float, (size_t)G * O);
+    A(values, float, G);
+    const size_t T = 2 * (size_t)G;
+    A(rootN, int32_t, T); A(rootW, float, T); A(rootP, float, T); A(rootBlock, int32_t, T);
+    A(nBlocks, int32_t, T); A(nEdges, int32_t, T); A(pending, int32_t, T);
+    A(eN, int32_t, T * D.EC); A(eW, float, T * D.EC); A(eP, float, T * D.EC);
+    A(eChild, int32_t, T * D.EC); A(eAct, int16_t, T * D.EC);
+    A(bStart, int32_t, T * D.BC); A(bCount, int32_t, T * D.BC); A(bOwner, int32_t, T * D.BC);
+    A(bParent, int32_t, T * D.BC); A(bMap, int32_t, T * D.BC); A(bShift, int32_t, T * D.BC);
+    A(rt, const int32_t *, G); A(rt_n, long long, G); A(rt_i, long long, G);
+    A(re, const double *, G); A(re_n, long long, G); A(re_i, long long, G);
+    A(ru, const double *, G); A(ru_n, long long, G); A(ru_i, long long, G);
+    A(rng_ctr, unsigned long long, G);
+    A(tr_moves, int16_t, (size_t)G * D.traj_plies);
+    A(tr_visits, int32_t, (size_t)G * D.traj_plies * O);
+    A(tr_winner, int32_t, G);
+    A(ctr, unsigned long long, C_N);
+#undef A
+    const size_t stn = std::max(G, 64);
+    ok = ok && (h->st_a = dalloc<int32_t>(h, stn)) && (h->st_b = dalloc<int32_t>(h, stn)) &&
+         (h->st_c = dalloc<int32_t>(h, stn)) && (h->st_d = dalloc<int32_t>(h, stn)) && (h->st_e = dalloc<int32_t>(h, stn));
+    h->st_bytes_n = (size_t)G * std::max(O, 17 * NC);
+    ok = ok && (h->st_bytes = dalloc<uint8_t>(h, h->st_bytes_n));
+    if (!ok) {
+        g_create_error = std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError());
+        az_engine_destroy(h);
+        return nullptr;
+    }
+    h->rng_bufs.assign((size_t)3 * G, nullptr);
+    if (cfg->num_blocks > 0) {
+        std::string terr;
+        h->tower = tower_create(H, W, O, cfg->num_blocks, cfg->channels > 0 ? cfg->channels : 256, cfg->tower_dtype, G, terr);
+        if (!h->tower) { g_create_error = "tower: " + terr; az_engine_destroy(h); return nullptr; }
+    }
+    hipLaunchKernelGGL(k_reset, dim3(G), dim3(64), 0, h->stream, D, (const int32_t *)nullptr, G, 0);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) {
+        g_create_error = std::string("reset kernel failed: ") + hipGetErrorString(hipGetLastError());
+        az_engine_destroy(h);
+        return nullptr;
+    }
+    return h;
+}
+
+extern "C" int az_engine_dims(az_engine *h, int32_t *n_slots, int32_t *cells, int32_t *actions)
+{
+    if (!h) return AZ_ERR_ARG;
+    if (n_slots) *n_slots = h->D.G;
+    if (cells) *cells = h->D.geo.NC;
+    if (actions) *actions = h->D.geo.O;
+    return AZ_OK;
+}
+
+static int check_slots(az_engine *h, const int32_t *slots, int n)
+{
+    if (!h) return AZ_ERR_ARG;
+    if (n < 0 || n > h->D.G || (n > 0 && !slots)) return set_err(h, AZ_ERR_ARG, "bad slot list");
+    for (int i = 0; i < n; i++)
+        if (slots[i] < 0 || slots[i] >= h->D.G) return set_err(h, AZ_ERR_ARG, "slot out of range");
+    return AZ_OK;
+}
+
+static int up(az_engine *h, int32_t *dst, const int32_t *src, int n)
+{
+    HIPCHK(hipMemcpyAsync(dst, src, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+    return AZ_OK;
+}
+
+extern "C" int az_games_reset(az_engine *h, const int32_t *slots, int32_t n)
+{
+    int rc = check_slots(h, slots, n);
+    if (rc) return rc;
+    if (n == 0) return AZ_OK;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if ((rc = up(h, h->st_a, slots, n))) return rc;
+    hipLaunchKernelGGL(k_reset, dim3(n), dim3(64), 0, h->stream, h->D, (const int32_t *)h->st_a, n, 0);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return AZ_OK;
+}
+
+extern "C" int az_state_copy(az_engine *dst, int32_t ds, az_engine *src, int32_t ss, int32_t ref)
+{
+    if (!dst || !src) return AZ_ERR_ARG;
+    az_engine *h = dst;
+    if (ds < 0 || ds >= dst->D.G || ss < 0 || ss >= src->D.G) return set_err(h, AZ_ERR_ARG, "slot out of range");
+    if (dst->D.geo.game != src->D.geo.game || dst->D.geo.H != src->D.geo.H || dst->D.geo.W != src->D.geo.W ||
+        dst->cfg.device != src->cfg.device)
+        return set_err(h, AZ_ERR_ARG, "engines differ in game, board or device");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(src->stream));
+    hipLaunchKernelGGL(k_state_copy, dim3(1), dim3(64), 0, dst->stream, dst->D, ds, src->D, ss, ref);
+    HIPCHK(hipStreamSynchronize(dst->stream));
+    return AZ_OK;
+}
+
+extern "C" int az_state_get(az_engine *h, int32_t slot, az_state_blob *out)
+{
+    if (!h || !out || slot < 0 || slot >= h->D.G) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int8_t ring[8][AZ_CP];
+    int32_t sc[S_N];
+    HIPCHK(hipMemcpyAsync(ring, h->D.ring + (size_t)slot * 8 * AZ_CP, sizeof ring, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(sc, h->D.sc + (size_t)slot * S_N, sizeof sc, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int head = sc[S_HEAD] & 7;
+    memcpy(out->board, ring[head], AZ_CP);
+    for (int t = 0; t < 7; t++) memcpy(out->history[t], ring[(head + 1 + t) & 7], AZ_CP);
+    out->current_player = sc[S_CUR]; out->ko = sc[S_KO]; out->turns = sc[S_TURNS]; out->n_history = sc[S_NHIST];
+    out->last1 = sc[S_LAST1]; out->last2 = sc[S_LAST2]; out->is_end_of_game = sc[S_END];
+    out->winner = sc[S_WIN]; out->winner_set = sc[S_WINSET];
+    out->passes_black = sc[S_PB]; out->passes_white = sc[S_PW];
+    out->num_black_prisoners = sc[S_PRB]; out->num_white_prisoners = sc[S_PRW]; out->stones_played = sc[S_STONES];
+    return AZ_OK;
+}
+
+extern "C" int az_state_set(az_engine *h, int32_t slot, const az_state_blob *in)
+{
+    if (!h || !in || slot < 0 || slot >= h->D.G) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int8_t ring[8][AZ_CP];
+    int32_t sc[S_N] = {0};
+    memcpy(ring[0], in->board, AZ_CP);
+    for (int t = 0; t < 7; t++) memcpy(ring[1 + t], in->history[t], AZ_CP);
+    sc[S_HEAD] = 0; sc[S_CUR] = in->current_player; sc[S_KO] = in->ko; sc[S_TURNS] = in->turns;
+    sc[S_NHIST] = in->n_history; sc[S_LAST1] = in->last1; sc[S_LAST2] = in->last2; sc[S_END] = in->is_end_of_game;
+    sc[S_WIN] = in->winner; sc[S_WINSET] = in->winner_set; sc[S_PB] = in->passes_black; sc[S_PW] = in->passes_white;
+    sc[S_PRB] = in->num_black_prisoners; sc[S_PRW] = in->num_white_prisoners; sc[S_STONES] = in->stones_played;
+    HIPCHK(hipMemcpyAsync(h->D.ring + (size_t)slot * 8 * AZ_CP, ring, sizeof ring, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->D.sc + (size_t)slot * S_N, sc, sizeof sc, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return AZ_OK;
+}
+
+extern "C" int az_rules_legal_mask(az_engine *h, const int32_t *slots, int32_t n, uint8_t *mask)
+{
+    int rc = check_slots(h, slots, n);
+    if (rc) return rc;
+    if (n == 0) return AZ_OK;
+    if (!mask) return set_err(h, AZ_ERR_ARG, "null output");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if ((rc = up(h, h->st_a, slots, n))) return rc;
+    hipLaunchKernelGGL(k_rules_mask, dim3(n), dim3(64), 0, h->stream, h->D, (const int32_t *)h->st_a, n, h->st_bytes);
+    HIPCHK(hipMemcpyAsync(mask, h->st_bytes, (size_t)n * h->D.geo.O, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return AZ_OK;
+}
+
+extern "C" int az_rules_do_move(az_engine *h, const int32_t *slots, int32_t n, const int32_t *actions,
+                                const int32_t *colors, int32_t *status, int32_t *ended)
+{
+    int rc = check_slots(h, slots, n);
+    if (rc) return rc;
+    if (n == 0) return AZ_OK;
+    if (!actions || !status) return set_err(h, AZ_ERR_ARG, "null argument");
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < i; j++)
+            if (slots[i] == slots[j]) return set_err(h, AZ_ERR_ARG, "duplicate slot in one do_move batch");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if ((rc = up(h, h->st_a, slots, n)) || (rc = up(h, h->st_b, actions, n))) return rc;
+    if (colors && (rc = up(h, h->st_c, colors, n))) return rc;
+    hipLaunchKernelGGL(k_rules_domove, dim3(n), dim3(64), 0, h->stream, h->D, (const int32_t *)h->st_a, n,
+                       (const int32_t *)h->st_b, colors ? (const int32_t *)h->st_c : (const int32_t *)nullptr, h->st_d, h->st_e);
+    std::vector<int32_t> en(n);
+    HIPCHK(hipMemcpyAsync(status, h->st_d, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(en.data(), h->st_e, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (ended) memcpy(ended, en.data(), sizeof(int32_t) * n);
+    return AZ_OK;
+}
+
+extern "C" int az_rules_winner(az_engine *h, const int32_t *slots, int32_t n, int32_t *winner)
+{
+    int rc = check_slots(h, slots, n);
+    if (rc) return rc;
+    if (n == 0) return AZ_OK;
+    if (!winner) return set_err(h, AZ_ERR_ARG, "null output");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if ((rc = up(h, h->st_a, slots, n))) return rc;
+    hipLaunchKernelGGL(k_rules_winner, dim3(n), dim3(64), 0, h->stream, h->D, (const int32_t *)h->st_a, n, h->st_d);
+    HIPCHK(hipMemcpyAsync(winner, h->st_d, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return AZ_OK;
+}
+
+extern "C" int az_state_transform(az_engine *h, int32_t slot, int32_t tid)
+{
+    if (!h || slot < 0 || slot >= h->D.G) return AZ_ERR_ARG;
+    if (tid < 0 || tid > 7 || (tid != 0 && h->D.geo.H != h->D.geo.W)) return set_err(h, AZ_ERR_ARG, "bad transform id");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_transform, dim3(1), dim3(64), 0, h->stream, h->D, slot, tid);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return AZ_OK;
+}
+
+extern "C" int az_features(az_engine *h, const int32_t *slots, int32_t n, const int32_t *tids, int8_t *planes)
+{
+    int rc = check_slots(h, slots, n);
+    if (rc) return rc;
+    if (n == 0) return AZ_OK;
+    if (!planes) return set_err(h, AZ_ERR_ARG, "null output");
+    if (tids)
+        for (int i = 0; i < n; i++)
+            if (tids[i] < 0 || tids[i] > 7 || (tids[i] != 0 && h->D.geo.H != h->D.geo.W))
+                return set_err(h, AZ_ERR_ARG, "bad transform id");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if ((rc = up(h, h->st_a, slots, n))) return rc;
+    if (tids && (rc = up(h, h->st_b, tids, n))) return rc;
+    hipLaunchKernelGGL(k_features, dim3(n), dim3(64), 0, h->stream, h->D, (const int32_t *)h->st_a, n,
+                       tids ? (const int32_t *)h->st_b : (const int32_t *)nullptr, (int8_t *)h->st_bytes);
+    HIPCHK(hipMemcpyAsync(planes, h->st_bytes, (size_t)n * 17 * h->D.geo.NC, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return AZ_OK;
+}
+
+// ---- search -------------------------------------------------------------
+
+extern "C" int az_search_begin(az_engine *h, const int32_t *slots, int32_t n, const int32_t *sides, const int32_t *dirichlet)
+{
+    int rc = check_slots(h, slots, n);
+    if (rc) return rc;
+    if (n == 0) return AZ_OK;
+    if (!sides || !dirichlet) return set_err(h, AZ_ERR_ARG, "null argument");
+    for (int i = 0; i < n; i++)
+        if (sides[i] < 0 || sides[i] > 1) return set_err(h, AZ_ERR_ARG, "side must be 0 or 1");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if ((rc = up(h, h->st_a, slots, n)) || (rc = up(h, h->st_b, sides, n)) || (rc = up(h, h->st_c, dirichlet, n))) return rc;
+    hipLaunchKernelGGL(k_begin, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->D, (const int32_t *)h->st_a, n,
+                       (const int32_t *)h->st_b, (const int32_t *)h->st_c);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return AZ_OK;
+}
+
+static int launch_select(az_engine *h)
+{
+    HIPCHK(hipMemsetAsync(h->D.ctr + C_NLEAVES, 0, sizeof(unsigned long long), h->stream));
+    hipLaunchKernelGGL(k_select, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
+    HIPCHK(hipGetLastError());
+    return AZ_OK;
+}
+
+extern "C" int az_search_step_select(az_engine *h, int32_t *n_leaves)
+{
+    if (!h) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc = launch_select(h);
+    if (rc) return rc;
+    unsigned long long nl = 0;
+    HIPCHK(hipMemcpyAsync(&nl, h->D.ctr + C_NLEAVES, sizeof nl, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (n_leaves) *n_leaves = (int32_t)nl;
+    return check_slot_errors(h);
+}
+
+extern "C" int az_leaf_batch(az_engine *h, int8_t *planes, uint8_t *valid)
+{
+    if (!h) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int G = h->D.G;
+    if (planes)
+        HIPCHK(hipMemcpyAsync(planes, h->D.planes, (size_t)G * 17 * h->D.geo.NC, hipMemcpyDeviceToHost, h->stream));
+    std::vector<int32_t> v(G);
+    HIPCHK(hipMemcpyAsync(v.data(), h->D.leaf_valid, sizeof(int32_t) * G, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (valid) for (int g = 0; g < G; g++) valid[g] = (uint8_t)v[g];
+    return AZ_OK;
+}
+
+static int evaluate(az_engine *h, const float *priors, const float *values)
+{
+    const int G = h->D.G, O = h->D.geo.O;
+    if ((priors == nullptr) != (values == nullptr)) return set_err(h, AZ_ERR_ARG, "priors and values must both be given or both NULL");
+    if (priors) {
+        HIPCHK(hipMemcpyAsync(h->D.priors, priors, sizeof(float) * (size_t)G * O, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->D.values, values, sizeof(float) * G, hipMemcpyHostToDevice, h->stream));
+        return AZ_OK;
+    }
+    if (!h->tower || !tower_ready(h->tower)) return set_err(h, AZ_ERR_NO_WEIGHTS, "no tower weights loaded and no priors injected");
+    std::string terr;
+    if (tower_forward(h->tower, h->D.planes, G, h->D.priors, h->D.values, h->stream, terr) != 0) {
+        h->error = "tower: " + terr;
+        return AZ_ERR_HIP;
+    }
+    h->tower_calls++;
+    h->tower_evals += G;
+    return AZ_OK;
+}
+
+extern "C" int az_search_step_finish(az_engine *h, const float *priors, const float *values)
+{
+    if (!h) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc = evaluate(h, priors, values);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_finish, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
+    HIPCHK(hipGetLastError());
+    h->steps++;
+    return check_slot_errors(h);
+}
+
+extern "C" int az_search_root_stats(az_engine *h, int32_t slot, int32_t side, int32_t *actions, int32_t *visits,
+                                    float *total_value, float *prior, int32_t *root_visits)
+{
+    if (!h || slot < 0 || slot >= h->D.G || side < 0 || side > 1) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const Dev &D = h->D;
+    const int t = 2 * slot + side;
+    int32_t rb = 0, rn = 0;
+    HIPCHK(hipMemcpyAsync(&rb, D.rootBlock + t, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&rn, D.rootN + t, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (root_visits) *root_visits = rn;
+    if (rb < 0) return 0;
+    int32_t start = 0, n = 0;
+    HIPCHK(hipMemcpy(&start, D.bStart + (size_t)t * D.BC + rb, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&n, D.bCount + (size_t)t * D.BC + rb, 4, hipMemcpyDeviceToHost));
+    const size_t e0 = (size_t)t * D.EC + start;
+    if (visits) HIPCHK(hipMemcpy(visits, D.eN + e0, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    if (total_value) HIPCHK(hipMemcpy(total_value, D.eW + e0, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (prior) HIPCHK(hipMemcpy(prior, D.eP + e0, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (actions) {
+        std::vector<int16_t> a(n);
+        HIPCHK(hipMemcpy(a.data(), D.eAct + e0, sizeof(int16_t) * n, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++) actions[i] = a[i];
+    }
+    return n;
+}
+
+extern "C" int az_search_choose(az_engine *h, int32_t slot, int32_t side, double u, int32_t *move)
+{
+    if (!h || !move || slot < 0 || slot >= h->D.G || side < 0 || side > 1) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_choose, dim3(1), dim3(64), 0, h->stream, h->D, slot, side, u, h->st_d);
+    HIPCHK(hipMemcpyAsync(move, h->st_d, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (*move == NOMOVE) return set_err(h, AZ_ERR_STATE, "root has no children");
+    return AZ_OK;
+}
+
+static int advance(az_engine *h, const int32_t *slots, int n, const int32_t *moves, int side_sel)
+{
+    int rc = check_slots(h, slots, n);
+    if (rc) return rc;
+    if (n == 0) return AZ_OK;
+    if (!moves) return set_err(h, AZ_ERR_ARG, "null moves");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if ((rc = up(h, h->st_a, slots, n)) || (rc = up(h, h->st_b, moves, n))) return rc;
+    hipLaunchKernelGGL(k_set_pending, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->D, (const int32_t *)h->st_a, n,
+                       (const int32_t *)h->st_b, side_sel);
+    hipLaunchKernelGGL(k_reroot, dim3(2 * h->D.G), dim3(64), 0, h->stream, h->D);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return AZ_OK;
+}
+
+extern "C" int az_search_advance_tree(az_engine *h, int32_t slot, int32_t side, int32_t move)
+{
+    if (!h || side < 0 || side > 1) return AZ_ERR_ARG;
+    return advance(h, &slot, 1, &move, side);
+}
+
+extern "C" int az_search_advance(az_engine *h, const int32_t *slots, int32_t n, const int32_t *moves)
+{
+    return advance(h, slots, n, moves, -1);
+}
+
+extern "C" int az_search_tree_size(az_engine *h, int32_t slot, int32_t side, int32_t *edges, int32_t *blocks)
+{
+    if (!h || slot < 0 || slot >= h->D.G || side < 0 || side > 1) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int t = 2 * slot + side;
+    if (edges) HIPCHK(hipMemcpy(edges, h->D.nEdges + t, 4, hipMemcpyDeviceToHost));
+    if (blocks) HIPCHK(hipMemcpy(blocks, h->D.nBlocks + t, 4, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+// ---- self-play machine -----------------------------------------------------
+
+extern "C" int az_selfplay_start(az_engine *h)
+{
+    if (!h) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_reset, dim3(h->D.G), dim3(64), 0, h->stream, h->D, (const int32_t *)nullptr, h->D.G, 1);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->started = true;
+    return AZ_OK;
+}
+
+static void launch_tail(az_engine *h)
+{
+    hipLaunchKernelGGL(k_finish, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
+    hipLaunchKernelGGL(k_move, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
+    hipLaunchKernelGGL(k_reroot, dim3(2 * h->D.G), dim3(64), 0, h->stream, h->D);
+}
+
+extern "C" int az_selfplay_run(az_engine *h, int32_t n_rounds)
+{
+    if (!h || n_rounds < 0) return AZ_ERR_ARG;
+    if (!h->started) return set_err(h, AZ_ERR_STATE, "az_selfplay_start has not been called");
+    if (!h->tower || !tower_ready(h->tower)) return set_err(h, AZ_ERR_NO_WEIGHTS, "no tower weights loaded");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    for (int r = 0; r < n_rounds; r++) {
+        HIPCHK(hipEventRecord(h->ev[0], h->stream));
+        int rc = launch_select(h);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(h->ev[1], h->stream));
+        if ((rc = evaluate(h, nullptr, nullptr))) return rc;
+        HIPCHK(hipEventRecord(h->ev[2], h->stream));
+        launch_tail(h);
+        HIPCHK(hipEventRecord(h->ev[3], h->stream));
+        HIPCHK(hipEventSynchronize(h->ev[3]));
+        float a = 0, b = 0, c = 0;
+        hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
+        hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
+        hipEventElapsedTime(&c, h->ev[2], h->ev[3]);
+        h->select_ms += a; h->tower_ms += b; h->finish_ms += c;
+        h->steps++;
+    }
+    HIPCHK(hipGetLastError());
+    return check_slot_errors(h);
+}
+
+extern "C" int az_selfplay_select(az_engine *h, int32_t *n_leaves)
+{
+    if (!h) return AZ_ERR_ARG;
+    if (!h->started) return set_err(h, AZ_ERR_STATE, "az_selfplay_start has not been called");
+    return az_search_step_select(h, n_leaves);
+}
+
+extern "C" int az_selfplay_finish(az_engine *h, const float *priors, const float *values)
+{
+    if (!h) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int rc = evaluate(h, priors, values);
+    if (rc) return rc;
+    launch_tail(h);
+    HIPCHK(hipGetLastError());
+    h->steps++;
+    return check_slot_errors(h);
+}
+
+extern "C" int az_selfplay_status(az_engine *h, int32_t *plies, int32_t *done)
+{
+    if (!h) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int G = h->D.G;
+    std::vector<int32_t> ph(G);
+    if (plies) HIPCHK(hipMemcpyAsync(plies, h->D.ply, sizeof(int32_t) * G, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(ph.data(), h->D.phase, sizeof(int32_t) * G, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (done) for (int g = 0; g < G; g++) done[g] = ph[g] == PH_GAME_DONE;
+    return AZ_OK;
+}
+
+extern "C" int az_trajectory_max_plies(az_engine *h) { return h ? h->D.traj_plies : AZ_ERR_ARG; }
+
+extern "C" int az_trajectory_pop(az_engine *h, int32_t slot, int16_t *moves, int32_t *visits, int32_t *winner, int32_t restart)
+{
+    if (!h || slot < 0 || slot >= h->D.G) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const Dev &D = h->D;
+    int32_t ph = 0, ply = 0, win = 0;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(&ph, D.phase + slot, 4, hipMemcpyDeviceToHost));
+    if (ph != PH_GAME_DONE) return set_err(h, AZ_ERR_STATE, "game in this slot is not finished");
+    HIPCHK(hipMemcpy(&ply, D.ply + slot, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&win, D.tr_winner + slot, 4, hipMemcpyDeviceToHost));
+    int np = std::min(ply, D.traj_plies);
+    if (D.record) {
+        if (moves) HIPCHK(hipMemcpy(moves, D.tr_moves + (size_t)slot * D.traj_plies, sizeof(int16_t) * np, hipMemcpyDeviceToHost));
+        if (visits)
+            HIPCHK(hipMemcpy(visits, D.tr_visits + (size_t)slot * D.traj_plies * D.geo.O, sizeof(int32_t) * (size_t)np * D.geo.O,
+                             hipMemcpyDeviceToHost));
+    }
+    if (winner) *winner = win;
+    if (restart) {
+        int32_t s = slot;
+        int rc = up(h, h->st_a, &s, 1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, h->stream, h->D, (const int32_t *)h->st_a, 1, 1);
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return np;
+}
+
+// ---- RNG replay streams ------------------------------------------------------
+
+extern "C" int az_rng_inject(az_engine *h, int32_t slot, const int32_t *tids, int64_t n_tids, const double *etas,
+                             int64_t n_etas, const double *unis, int64_t n_unis)
+{
+    if (!h || slot < 0 || slot >= h->D.G || n_tids < 0 || n_etas < 0 || n_unis < 0) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const void *src[3] = {tids, etas, unis};
+    const size_t bytes[3] = {sizeof(int32_t) * (size_t)n_tids, sizeof(double) * (size_t)n_etas, sizeof(double) * (size_t)n_unis};
+    void *dev[3] = {nullptr, nullptr, nullptr};
+    for (int k = 0; k < 3; k++) {
+        void *&old = h->rng_bufs[(size_t)3 * slot + k];
+        if (old) { hipFree(old); old = nullptr; }
+        if (bytes[k]) {
+            HIPCHK(hipMalloc(&dev[k], bytes[k]));
+            old = dev[k];
+            HIPCHK(hipMemcpy(dev[k], src[k], bytes[k], hipMemcpyHostToDevice));
+        }
+    }
+    long long zero = 0, n0 = n_tids, n1 = n_etas, n2 = n_unis;
+    HIPCHK(hipMemcpy(h->D.rt + slot, &dev[0], sizeof(void *), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->D.re + slot, &dev[1], sizeof(void *), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->D.ru + slot, &dev[2], sizeof(void *), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->D.rt_n + slot, &n0, 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->D.re_n + slot, &n1, 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->D.ru_n + slot, &n2, 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->D.rt_i + slot, &zero, 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->D.re_i + slot, &zero, 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->D.ru_i + slot, &zero, 8, hipMemcpyHostToDevice));
+    return AZ_OK;
+}
+
+extern "C" int az_rng_cursor(az_engine *h, int32_t slot, int64_t *i_tids, int64_t *i_etas, int64_t *i_unis)
+{
+    if (!h || slot < 0 || slot >= h->D.G) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    long long v[3];
+    HIPCHK(hipMemcpy(&v[0], h->D.rt_i + slot, 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&v[1], h->D.re_i + slot, 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&v[2], h->D.ru_i + slot, 8, hipMemcpyDeviceToHost));
+    if (i_tids) *i_tids = v[0];
+    if (i_etas) *i_etas = v[1];
+    if (i_unis) *i_unis = v[2];
+    return AZ_OK;
+}
+
+// ---- tower ---------------------------------------------------------------------
+
+extern "C" size_t az_tower_blob_floats(az_engine *h) { return (h && h->tower) ? tower_blob_floats(h->tower) : 0; }
+
+extern "C" int az_tower_load_weights(az_engine *h, const float *blob, size_t n)
+{
+    if (!h || !blob) return AZ_ERR_ARG;
+    if (!h->tower) return set_err(h, AZ_ERR_ARG, "engine was created with num_blocks = 0 (no tower)");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    std::string terr;
+    if (tower_load(h->tower, blob, n, h->stream, terr) != 0) { h->error = "tower: " + terr; return AZ_ERR_ARG; }
+    return AZ_OK;
+}
+
+extern "C" int az_tower_forward(az_engine *h, const int8_t *planes, int32_t B, float *out_p, float *out_v)
+{
+    if (!h || !planes || !out_p || !out_v || B < 1) return AZ_ERR_ARG;
+    if (!h->tower || !tower_ready(h->tower)) return set_err(h, AZ_ERR_NO_WEIGHTS, "no tower weights loaded");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int G = h->D.G, O = h->D.geo.O, NC = h->D.geo.NC;
+    std::string terr;
+    for (int b0 = 0; b0 < B; b0 += G) {
+        int nb = std::min(G, B - b0);
+        HIPCHK(hipMemcpyAsync(h->D.planes, planes + (size_t)b0 * 17 * NC, (size_t)nb * 17 * NC, hipMemcpyHostToDevice, h->stream));
+        if (tower_forward(h->tower, h->D.planes, nb, h->D.priors, h->D.values, h->stream, terr) != 0) {
+            h->error = "tower: " + terr;
+            return AZ_ERR_HIP;
+        }
+        HIPCHK(hipMemcpyAsync(out_p + (size_t)b0 * O, h->D.priors, sizeof(float) * (size_t)nb * O, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(out_v + b0, h->D.values, sizeof(float) * nb, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return AZ_OK;
+}
+
+extern "C" double az_tower_flops_per_eval(az_engine *h) { return (h && h->tower) ? tower_flops_per_eval(h->tower) : 0.0; }
+
+// ---- measurement -----------------------------------------------------------------
+
+extern "C" int az_counters_get(az_engine *h, az_counters *out)
+{
+    if (!h || !out) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    unsigned long long c[C_N];
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(c, h->D.ctr, sizeof c, hipMemcpyDeviceToHost));
+    out->steps = h->steps; out->evals = c[C_EVALS]; out->moves = c[C_MOVES]; out->games_finished = c[C_GAMES];
+    out->levels = c[C_LEVELS]; out->children_scanned = c[C_CHILDREN]; out->edges_created = c[C_EDGES];
+    out->rule_moves = c[C_RULEMOVES];
+    out->tower_ms = h->tower_ms; out->select_ms = h->select_ms; out->finish_ms = h->finish_ms;
+    out->tower_calls = h->tower_calls; out->tower_evals = h->tower_evals;
+    return AZ_OK;
+}
+
+extern "C" int az_counters_reset(az_engine *h)
+{
+    if (!h) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemset(h->D.ctr, 0, sizeof(unsigned long long) * C_N));
+    h->tower_ms = h->select_ms = h->finish_ms = 0;
+    h->tower_calls = h->tower_evals = h->steps = 0;
+    return AZ_OK;
+}
+
+extern "C" int az_sync(az_engine *h)
+{
+    if (!h) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return AZ_OK;
+}

@@ -1,0 +1,678 @@
+// Search / rules kernels: one wavefront (one 64-thread workgroup) per game or tree.
+#pragma once
+#include "az_device.h"
+
+// ---------------------------------------------------------------------------
+// RNG draws (wave-uniform; lane 0 advances the cursors)
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ unsigned long long rng_u64(const Dev &D, int g)
+{
+    unsigned long long c = D.rng_ctr[g];
+    WSYNC();
+    if (lane_id() == 0) D.rng_ctr[g] = c + 1;
+    return mix64(D.seed + 0x9E3779B97F4A7C15ULL * (unsigned long long)(g + 1) + mix64(c));
+}
+
+__device__ __forceinline__ double rng_u01(const Dev &D, int g)
+{
+    return (double)(rng_u64(D, g) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+__device__ int rng_tid(const Dev &D, int g)
+{
+    if (D.rng_replay) {
+        long long i = D.rt_i[g];
+        WSYNC();
+        if (i >= D.rt_n[g]) { if (lane_id() == 0) D.err[g] = -5; return 0; }
+        int v = D.rt[g][i];
+        if (lane_id() == 0) D.rt_i[g] = i + 1;
+        return v;
+    }
+    return (int)(rng_u64(D, g) % (unsigned long long)D.transform_types);
+}
+
+__device__ double rng_uniform(const Dev &D, int g)
+{
+    if (D.rng_replay) {
+        long long i = D.ru_i[g];
+        WSYNC();
+        if (i >= D.ru_n[g]) { if (lane_id() == 0) D.err[g] = -5; return 0.0; }
+        double v = D.ru[g][i];
+        if (lane_id() == 0) D.ru_i[g] = i + 1;
+        return v;
+    }
+    return rng_u01(D, g);
+}
+
+// gamma(alpha, 1) for alpha <= 1 (Ahrens-Dieter GS, the algorithm CPython's
+// random.gammavariate uses); per-lane independent draw from a hashed stream
+__device__ double gamma_small(double alpha, unsigned long long key)
+{
+    double x = 0.0;
+    for (int it = 0; it < 64; it++) {
+        double u = (double)(mix64(key + 2 * it) >> 11) * (1.0 / 9007199254740992.0);
+        double u1 = (double)(mix64(key + 2 * it + 1) >> 11) * (1.0 / 9007199254740992.0);
+        double bb = (2.718281828459045 + alpha) / 2.718281828459045;
+        double p = bb * u;
+        x = p <= 1.0 ? pow(p, 1.0 / alpha) : -log((bb - p) / alpha);
+        if (p > 1.0) { if (u1 <= pow(x, alpha - 1.0)) break; }
+        else if (u1 <= exp(-x)) break;
+    }
+    return x;
+}
+
+// P <- (1-eps)*P + eps*eta over the root's children in insertion order
+// (search/mcts.py:285-291; eta is NOT normalised, math_helper.py:13-17)
+__device__ void apply_noise(const Dev &D, int g, int t)
+{
+    const int lane = lane_id();
+    int rb = D.rootBlock[t];
+    if (rb < 0) return;
+    size_t tb = (size_t)t * D.EC, bb = (size_t)t * D.BC;
+    int start = D.bStart[bb + rb], n = D.bCount[bb + rb];
+    float keep = (float)(1.0 - D.d_epsilon);
+    long long base = 0;
+    unsigned long long key = 0;
+    if (D.rng_replay) {
+        base = D.re_i[g];
+        WSYNC();
+        if (base + n > D.re_n[g]) { if (lane == 0) D.err[g] = -5; return; }
+        if (lane == 0) D.re_i[g] = base + n;
+    } else {
+        key = rng_u64(D, g);
+    }
+    for (int c = lane; c < n; c += AZ_WAVE) {
+        double eta = D.rng_replay ? D.re[g][base + c] : gamma_small(D.d_alpha, key + 1000ULL * (unsigned long long)(c + 1));
+        float p = D.eP[tb + start + c];
+        float a = keep * p;
+        D.eP[tb + start + c] = a + (float)(D.d_epsilon * eta);
+    }
+    WSYNC();
+}
+
+// ---------------------------------------------------------------------------
+// select: descend one tree per slot to a leaf, replaying the rules on the way
+// (search/mcts.py:173-217, :261-280)
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(64) void k_select(Dev D)
+{
+    __shared__ WLds L;
+    const int g = blockIdx.x;
+    const int lane = lane_id();
+    const Geo G = D.geo;
+    int phase = D.phase[g];
+    if (lane == 0) D.leaf_valid[g] = 0;
+    if (phase != PH_NEED_START && phase != PH_IN_SEARCH) return;
+    if (D.err[g] != 0) return;
+    const int side = D.side[g];
+    const int t = 2 * g + side;
+    const size_t tb = (size_t)t * D.EC, bb = (size_t)t * D.BC;
+
+    PS s;
+    load_scalars(D, g, s);
+    load_ring(D, g, L);
+    if (G.game == G_GO) { s.is_end = 0; s.passes_b = 0; s.passes_w = 0; }  // GameState.copy(), env/go.py:242
+
+    int root_expand = 0;
+    int rootN = D.rootN[t];
+    WSYNC();
+    if (phase == PH_NEED_START) {
+        rootN += 1;  // self._root.visit(), mcts.py:261
+        if (D.rootBlock[t] < 0) {
+            root_expand = 1;
+        } else {
+            if (D.dflag[g]) apply_noise(D, g, t);
+            phase = PH_IN_SEARCH;
+            if (lane == 0) { D.phase[g] = PH_IN_SEARCH; D.pdone[g] = 0; }
+            if (D.max_playout == 0) {
+                if (lane == 0) { D.phase[g] = PH_SEARCH_DONE; D.rootN[t] = rootN; }
+                return;
+            }
+        }
+    }
+    int node = NODE_ROOT, node_block = -1, depth = 0;
+    unsigned long long levels = 0, scanned = 0;
+    if (!root_expand) {
+        rootN += 1;  // node.visit() of the root inside _playout
+        int blk = D.rootBlock[t];
+        int parentN = rootN;
+        while (blk >= 0) {
+            int start = D.bStart[bb + blk], n = D.bCount[bb + blk];
+            // Q+U in float32, left to right as mcts.py:88-90; first maximum wins
+            float sq = (float)sqrt((double)parentN);
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+            for (int c = lane; c < n; c += AZ_WAVE) {
+                int N = D.eN[tb + start + c];
+                float Wv = D.eW[tb + start + c], P = D.eP[tb + start + c];
+                float u = 5.0f * P;
+                u = u * sq;
+                u = u / (1.0f + (float)N);
+                float q = N == 0 ? 0.0f : Wv / (float)N;
+                float v = q + u;
+                if (v > bv) { bv = v; bi = c; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                float ov = __shfl_xor(bv, o, 64);
+                int oi = __shfl_xor(bi, o, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            levels++; scanned += (unsigned long long)n;
+            if (bi == 0x7fffffff) bi = 0;  // all-NaN scores: Python's max keeps the first item
+            int e = start + bi;
+            if (depth >= D.MAXD) { if (lane == 0) D.err[g] = -6; return; }
+            if (lane == 0) {
+                D.path_node[(size_t)g * D.MAXD + depth] = node;
+                D.path_player[(size_t)g * D.MAXD + depth] = (int8_t)s.cur;
+            }
+            depth++;
+            int a = D.eAct[tb + e];
+            dev_do_move(G, L, s, a);
+            int N = D.eN[tb + e] + 1;  // child.visit()
+            WSYNC();
+            if (lane == 0) D.eN[tb + e] = N;
+            node = e; node_block = blk;
+            parentN = N;
+            blk = D.eChild[tb + e];
+        }
+    }
+    if (lane == 0) D.rootN[t] = rootN;
+
+    // leaf: transform id, legality on the un-transformed state, evaluator input
+    int tid = D.transform_on ? rng_tid(D, g) : 0;
+    int nlegal = dev_legal_mask(G, L, s);
+    uint8_t *gm = D.leaf_mask + (size_t)g * AZ_OP;
+    for (int i = lane; i < AZ_OP / 4; i += AZ_WAVE)
+        reinterpret_cast<int *>(gm)[i] = reinterpret_cast<int *>(L.mask)[i];
+    int terminal = (nlegal == 0) || s.is_end;
+    int win = 0;
+    if (terminal && !root_expand) win = dev_winner(G, L, s);
+    dev_features(G, L, s, tid, D.planes + (size_t)g * 17 * G.NC);
+    if (lane == 0) {
+        D.leaf_valid[g] = 1;
+        D.leaf_node[g] = node;
+        D.leaf_block[g] = node_block;
+        D.leaf_player[g] = s.cur;
+        D.leaf_end[g] = terminal;
+        D.leaf_winner[g] = win;
+        D.leaf_tid[g] = tid;
+        D.leaf_root[g] = root_expand;
+        D.path_len[g] = depth;
+        atomicAdd(&D.ctr[C_LEVELS], levels);
+        atomicAdd(&D.ctr[C_CHILDREN], scanned);
+        atomicAdd(&D.ctr[C_RULEMOVES], (unsigned long long)depth);
+        atomicAdd(&D.ctr[C_NLEAVES], 1ULL);
+        atomicAdd(&D.ctr[C_EVALS], 1ULL);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// finish: expand or terminal value, then backup (mcts.py:217-232, 196-202, 283)
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(64) void k_finish(Dev D)
+{
+    const int g = blockIdx.x;
+    const int lane = lane_id();
+    const Geo G = D.geo;
+    if (!D.leaf_valid[g] || D.err[g] != 0) return;
+    const int side = D.side[g];
+    const int t = 2 * g + side;
+    const size_t tb = (size_t)t * D.EC, bb = (size_t)t * D.BC;
+    const int root_expand = D.leaf_root[g];
+    const int node = D.leaf_node[g];
+    const int player = D.leaf_player[g];
+    const int tid = D.leaf_tid[g];
+    float v = D.values[g];
+    const uint8_t *mask = D.leaf_mask + (size_t)g * AZ_OP;
+    const float *pri = D.priors + (size_t)g * G.O;
+    WSYNC();
+    const int expandable = root_expand ? 1 : !D.leaf_end[g];
+    if (expandable) {
+        int bi = D.nBlocks[t], start = D.nEdges[t];
+        // count legal children first so that a full arena is detected before writing
+        int n = 0;
+        for (int i0 = 0; i0 < G.O; i0 += AZ_WAVE) {
+            int i = i0 + lane;
+            int legal = 0;
+            if (i < G.O) {
+                int a = (i < G.NC && tid) ? transform_src(i, G.H, G.W, tid) : i;
+                legal = mask[a];
+            }
+            n += __popcll(__ballot(legal));
+        }
+        if (bi >= D.BC || start + n > D.EC) { if (lane == 0) D.err[g] = -4; return; }
+        int off = 0;
+        for (int i0 = 0; i0 < G.O; i0 += AZ_WAVE) {
+            int i = i0 + lane;
+            int legal = 0, a = 0;
+            if (i < G.O) {
+                a = (i < G.NC && tid) ? transform_src(i, G.H, G.W, tid) : i;
+                legal = mask[a];
+            }
+            unsigned long long bal = __ballot(legal);
+            int pos = off + __popcll(bal & ((1ULL << lane) - 1ULL));
+            if (legal) {
+                size_t e = tb + start + pos;
+                D.eN[e] = 0; D.eW[e] = 0.0f; D.eP[e] = pri[i]; D.eChild[e] = -1; D.eAct[e] = (int16_t)a;
+            }
+            off += __popcll(bal);
+        }
+        if (lane == 0) {
+            if (n > 0) {
+                D.bStart[bb + bi] = start; D.bCount[bb + bi] = n;
+                D.bOwner[bb + bi] = node; D.bParent[bb + bi] = D.leaf_block[g];
+                D.nBlocks[t] = bi + 1; D.nEdges[t] = start + n;
+                if (node == NODE_ROOT) D.rootBlock[t] = bi; else D.eChild[tb + node] = bi;
+                atomicAdd(&D.ctr[C_EDGES], (unsigned long long)n);
+            }
+            // node.update(value): raw value at the root, -player*value below it
+            float add = root_expand ? v : (float)(-player) * v;
+            if (node == NODE_ROOT) D.rootW[t] += add; else D.eW[tb + node] += add;
+        }
+    } else {
+        v = (float)D.leaf_winner[g];  // value = state.get_winner()
+        if (lane == 0) {
+            float add = (float)(-player) * v;
+            if (node == NODE_ROOT) D.rootW[t] += add; else D.eW[tb + node] += add;
+        }
+    }
+    WSYNC();
+    if (root_expand) {
+        if (D.dflag[g]) apply_noise(D, g, t);
+        if (lane == 0) {
+            D.pdone[g] = 0;
+            D.phase[g] = D.max_playout == 0 ? PH_SEARCH_DONE : PH_IN_SEARCH;
+        }
+        return;
+    }
+    // ancestors: node.update(-current_player * simres_value)
+    int plen = D.path_len[g];
+    for (int d = lane; d < plen; d += AZ_WAVE) {
+        int nd = D.path_node[(size_t)g * D.MAXD + d];
+        float add = (float)(-(int)D.path_player[(size_t)g * D.MAXD + d]) * v;
+        if (nd == NODE_ROOT) D.rootW[t] += add; else D.eW[tb + nd] += add;
+    }
+    if (lane == 0) {
+        int pd = D.pdone[g] + 1;
+        D.pdone[g] = pd;
+        if (pd >= D.max_playout) D.phase[g] = PH_SEARCH_DONE;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// weighted_random_choice over N_a / sum N (search/mcts.py:234-243,
+// math_helper.py:20-23, CPython random.choices): returns the action
+// ---------------------------------------------------------------------------
+
+__device__ int dev_choose(const Dev &D, WLds &L, int t, double u, int *n_out)
+{
+    const int lane = lane_id();
+    size_t tb = (size_t)t * D.EC, bb = (size_t)t * D.BC;
+    int rb = D.rootBlock[t];
+    if (rb < 0) { *n_out = 0; return NOMOVE; }
+    int start = D.bStart[bb + rb], n = D.bCount[bb + rb];
+    *n_out = n;
+    for (int c = lane; c < n; c += AZ_WAVE) L.libs[c] = D.eN[tb + start + c];
+    WSYNC();
+    if (lane == 0) {
+        long long total = 0;
+        for (int c = 0; c < n; c++) total += L.libs[c];
+        double acc = 0.0;
+        for (int c = 0; c < n; c++) {
+            double w = (double)L.libs[c] / (double)total;
+            acc = c == 0 ? w : acc + w;
+            L.cum[c] = acc;
+        }
+        double x = u * (L.cum[n - 1] + 0.0);
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            int mid = (lo + hi) / 2;
+            if (x < L.cum[mid]) hi = mid; else lo = mid + 1;
+        }
+        L.tmp[0] = lo;
+    }
+    WSYNC();
+    int idx = L.tmp[0];
+    WSYNC();
+    return D.eAct[tb + start + idx];
+}
+
+// one ply of Game.start for every slot whose search is complete
+// (game/gameplay.py:52-69): pick the move, log it, play it, queue the re-roots
+__global__ __launch_bounds__(64) void k_move(Dev D)
+{
+    __shared__ WLds L;
+    const int g = blockIdx.x;
+    const int lane = lane_id();
+    const Geo G = D.geo;
+    if (D.phase[g] != PH_SEARCH_DONE || !D.automode[g] || D.err[g] != 0) return;
+    const int side = D.side[g];
+    const int t = 2 * g + side;
+    const size_t tb = (size_t)t * D.EC, bb = (size_t)t * D.BC;
+    double u = rng_uniform(D, g);
+    int n = 0;
+    int mv = dev_choose(D, L, t, u, &n);
+    if (mv == NOMOVE) { if (lane == 0) D.err[g] = -7; return; }
+    int ply = D.ply[g];
+    if (D.record && ply < D.traj_plies) {
+        int32_t *row = D.tr_visits + ((size_t)g * D.traj_plies + ply) * G.O;
+        for (int i = lane; i < G.O; i += AZ_WAVE) row[i] = 0;
+        WSYNC();
+        int start = D.bStart[bb + D.rootBlock[t]];
+        for (int c = lane; c < n; c += AZ_WAVE) row[D.eAct[tb + start + c]] = D.eN[tb + start + c];
+        if (lane == 0) D.tr_moves[(size_t)g * D.traj_plies + ply] = (int16_t)mv;
+    }
+    PS s;
+    load_scalars(D, g, s);
+    load_ring(D, g, L);
+    dev_do_move(G, L, s, mv);
+    store_ring(D, g, L);
+    store_scalars(D, g, s);
+    int over = s.is_end || s.turns > D.max_turn;
+    int win = 0;
+    if (over) win = dev_winner(G, L, s);
+    if (lane == 0) {
+        D.pending[2 * g] = mv;
+        D.pending[2 * g + 1] = mv;
+        D.ply[g] = ply + 1;
+        D.side[g] = side ^ 1;
+        atomicAdd(&D.ctr[C_MOVES], 1ULL);
+        if (over) {
+            D.tr_winner[g] = win;
+            D.phase[g] = PH_GAME_DONE;
+            atomicAdd(&D.ctr[C_GAMES], 1ULL);
+        } else {
+            D.phase[g] = PH_NEED_START;
+            D.dflag[g] = s.turns <= D.dirichlet_before;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// update_with_move (search/mcts.py:336-346): keep the chosen child's subtree,
+// compacting the tree's arena in place (blocks keep their creation order, so
+// every block only ever moves towards lower addresses)
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(64) void k_reroot(Dev D)
+{
+    const int t = blockIdx.x;
+    const int lane = lane_id();
+    const int mv = D.pending[t];
+    if (mv == NOMOVE) return;
+    WSYNC();
+    if (lane == 0) D.pending[t] = NOMOVE;
+    const size_t tb = (size_t)t * D.EC, bb = (size_t)t * D.BC;
+    const int rb = D.rootBlock[t];
+    int found = -1;
+    if (rb >= 0) {
+        int start = D.bStart[bb + rb], n = D.bCount[bb + rb];
+        for (int c0 = 0; c0 < n; c0 += AZ_WAVE) {
+            int c = c0 + lane;
+            int hit = (c < n) && (D.eAct[tb + start + c] == mv);
+            unsigned long long bal = __ballot(hit);
+            if (bal) { found = start + __ffsll((long long)bal) - 1; break; }
+        }
+    }
+    if (found < 0) {  // MCTreeNode(None, 1.0)
+        if (lane == 0) {
+            D.rootN[t] = 0; D.rootW[t] = 0.0f; D.rootP[t] = 1.0f;
+            D.rootBlock[t] = -1; D.nBlocks[t] = 0; D.nEdges[t] = 0;
+        }
+        return;
+    }
+    const int r = D.eChild[tb + found];
+    const int nN = D.eN[tb + found];
+    const float nW = D.eW[tb + found], nP = D.eP[tb + found];
+    const int nb = D.nBlocks[t];
+    WSYNC();
+    if (lane == 0) { D.rootN[t] = nN; D.rootW[t] = nW; D.rootP[t] = nP; }
+    if (r < 0) {
+        if (lane == 0) { D.rootBlock[t] = -1; D.nBlocks[t] = 0; D.nEdges[t] = 0; }
+        return;
+    }
+    // 1. liveness: a block lives iff it is r or its parent block lives (parent index < own index)
+    for (int b = lane; b <= r; b += AZ_WAVE) D.bMap[bb + b] = (b == r);
+    WSYNC();
+    for (int c0 = r + 1; c0 < nb; c0 += AZ_WAVE) {
+        int b = c0 + lane;
+        int valid = b < nb;
+        int par = valid ? D.bParent[bb + b] : -1;
+        int live = valid && par >= 0 && par < c0 && D.bMap[bb + par] != 0;
+        unsigned long long m = __ballot(live);
+        for (;;) {
+            int nl = valid && !live && par >= c0 && ((m >> (par - c0)) & 1ULL);
+            live |= nl;
+            unsigned long long m2 = __ballot(live);
+            if (m2 == m) break;
+            m = m2;
+        }
+        if (valid) D.bMap[bb + b] = live;
+        WSYNC();
+    }
+    // 2. new block index (bMap) and address shift (bShift) of every live block
+    int nbNew = 0, neNew = 0;
+    for (int c0 = r; c0 < nb; c0 += AZ_WAVE) {
+        int b = c0 + lane;
+        int live = (b < nb) && D.bMap[bb + b] != 0;
+        int cnt = live ? D.bCount[bb + b] : 0;
+        int st = live ? D.bStart[bb + b] : 0;
+        unsigned long long m = __ballot(live);
+        int idx = nbNew + __popcll(m & ((1ULL << lane) - 1ULL));
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        int excl = incl - cnt;
+        int tot = __shfl(incl, 63, 64);
+        WSYNC();
+        if (b < nb) {
+            D.bMap[bb + b] = live ? idx : -1;
+            D.bShift[bb + b] = live ? st - (neNew + excl) : 0;
+        }
+        nbNew += __popcll(m);
+        neNew += tot;
+    }
+    WSYNC();
+    // 3. slide edges and rewrite the block table, lowest block first
+    for (int b = r; b < nb; b++) {
+        int ni = D.bMap[bb + b];
+        if (ni < 0) continue;
+        int os = D.bStart[bb + b], cnt = D.bCount[bb + b], sh = D.bShift[bb + b];
+        int owner = D.bOwner[bb + b], par = D.bParent[bb + b];
+        int ns = os - sh;
+        int nowner = -1, npar = -1;
+        if (b != r) { nowner = owner - D.bShift[bb + par]; npar = D.bMap[bb + par]; }
+        WSYNC();
+        for (int c0 = 0; c0 < cnt; c0 += AZ_WAVE) {
+            int c = c0 + lane;
+            int N = 0, ch = -1; float Wv = 0, P = 0; int16_t a = 0;
+            if (c < cnt) {
+                size_t e = tb + os + c;
+                N = D.eN[e]; Wv = D.eW[e]; P = D.eP[e]; ch = D.eChild[e]; a = D.eAct[e];
+                if (ch >= 0) ch = D.bMap[bb + ch];
+            }
+            WSYNC();
+            if (c < cnt) {
+                size_t e = tb + ns + c;
+                D.eN[e] = N; D.eW[e] = Wv; D.eP[e] = P; D.eChild[e] = ch; D.eAct[e] = a;
+            }
+            WSYNC();
+        }
+        if (lane == 0) {
+            D.bStart[bb + ni] = ns; D.bCount[bb + ni] = cnt;
+            D.bOwner[bb + ni] = nowner; D.bParent[bb + ni] = npar;
+        }
+        WSYNC();
+    }
+    if (lane == 0) { D.rootBlock[t] = 0; D.nBlocks[t] = nbNew; D.nEdges[t] = neNew; }
+}
+
+// ---------------------------------------------------------------------------
+// batched rules / features entry kernels (env modules, state_converter)
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ void init_state(const Geo &G, WLds &L, PS &s)
+{
+    int *p = reinterpret_cast<int *>(&L.ring[0][0]);
+    for (int q = lane_id(); q < 8 * AZ_CP / 4; q += AZ_WAVE) p[q] = 0;
+    WSYNC();
+    s.head = 0; s.cur = 1; s.ko = -1; s.turns = 0; s.nhist = 0; s.last1 = NOMOVE; s.last2 = NOMOVE;
+    s.is_end = 0; s.winner = 0; s.winner_set = 0; s.passes_b = 0; s.passes_w = 0; s.pris_b = 0; s.pris_w = 0;
+    s.stones = 0;
+    if (G.game == G_REVERSI) {  // env/reversi.py:20-23
+        int h = G.H / 2;
+        if (lane_id() == 0) {
+            L.ring[0][(h - 1) * G.W + (h - 1)] = -1; L.ring[0][h * G.W + h] = -1;
+            L.ring[0][h * G.W + (h - 1)] = 1; L.ring[0][(h - 1) * G.W + h] = 1;
+        }
+        s.stones = 4;
+        WSYNC();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_reset(Dev D, const int32_t *slots, int n, int automode)
+{
+    __shared__ WLds L;
+    int q = blockIdx.x;
+    if (q >= n) return;
+    int g = slots ? slots[q] : q;
+    PS s;
+    init_state(D.geo, L, s);
+    store_ring(D, g, L);
+    store_scalars(D, g, s);
+    if (lane_id() == 0) {
+        D.phase[g] = automode ? PH_NEED_START : PH_IDLE;
+        D.side[g] = 0; D.dflag[g] = automode ? (0 <= D.dirichlet_before) : 0; D.pdone[g] = 0;
+        D.automode[g] = automode; D.ply[g] = 0; D.err[g] = 0; D.leaf_valid[g] = 0; D.tr_winner[g] = 0;
+        for (int k = 0; k < 2; k++) {
+            int t = 2 * g + k;
+            D.rootN[t] = 0; D.rootW[t] = 0.0f; D.rootP[t] = 1.0f; D.rootBlock[t] = -1;
+            D.nBlocks[t] = 0; D.nEdges[t] = 0; D.pending[t] = NOMOVE;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_rules_mask(Dev D, const int32_t *slots, int n, uint8_t *out)
+{
+    __shared__ WLds L;
+    int q = blockIdx.x;
+    if (q >= n) return;
+    int g = slots[q];
+    PS s;
+    load_scalars(D, g, s);
+    load_ring(D, g, L);
+    dev_legal_mask(D.geo, L, s);
+    for (int i = lane_id(); i < D.geo.O; i += AZ_WAVE) out[(size_t)q * D.geo.O + i] = L.mask[i];
+}
+
+__global__ __launch_bounds__(64) void k_rules_domove(Dev D, const int32_t *slots, int n, const int32_t *actions,
+                                                     const int32_t *colors, int32_t *status, int32_t *ended)
+{
+    __shared__ WLds L;
+    int q = blockIdx.x;
+    if (q >= n) return;
+    int g = slots[q], a = actions[q];
+    PS s;
+    load_scalars(D, g, s);
+    load_ring(D, g, L);
+    int color = colors ? colors[q] : 0;
+    if (color != 0) s.cur = color;  // legality is judged for the stated colour (env/go.py:511-514)
+    dev_legal_mask(D.geo, L, s);
+    int ok = a >= 0 && a < D.geo.O && L.mask[a];
+    WSYNC();
+    if (!ok) {
+        if (lane_id() == 0) { status[q] = -3; ended[q] = s.is_end; }
+        return;
+    }
+    dev_do_move(D.geo, L, s, a);
+    store_ring(D, g, L);
+    store_scalars(D, g, s);
+    if (lane_id() == 0) { status[q] = 0; ended[q] = s.is_end; }
+}
+
+__global__ __launch_bounds__(64) void k_rules_winner(Dev D, const int32_t *slots, int n, int32_t *out)
+{
+    __shared__ WLds L;
+    int q = blockIdx.x;
+    if (q >= n) return;
+    int g = slots[q];
+    PS s;
+    load_scalars(D, g, s);
+    load_ring(D, g, L);
+    int w = dev_winner(D.geo, L, s);
+    if (lane_id() == 0) out[q] = w;
+}
+
+__global__ __launch_bounds__(64) void k_features(Dev D, const int32_t *slots, int n, const int32_t *tids, int8_t *out)
+{
+    __shared__ WLds L;
+    int q = blockIdx.x;
+    if (q >= n) return;
+    int g = slots[q];
+    PS s;
+    load_scalars(D, g, s);
+    load_ring(D, g, L);
+    dev_features(D.geo, L, s, tids ? tids[q] : 0, out + (size_t)q * 17 * D.geo.NC);
+}
+
+// GameState.transform(id): board and the 7 history boards, in place
+__global__ __launch_bounds__(64) void k_transform(Dev D, int g, int tid)
+{
+    __shared__ WLds L;
+    __shared__ int8_t T[8][AZ_CP];
+    PS s;
+    load_scalars(D, g, s);
+    load_ring(D, g, L);
+    for (int i = lane_id(); i < D.geo.NC; i += AZ_WAVE) {
+        int src = transform_src(i, D.geo.H, D.geo.W, tid);
+        for (int r = 0; r < 8; r++) T[r][i] = L.ring[r][src];
+    }
+    WSYNC();
+    for (int i = lane_id(); i < D.geo.NC; i += AZ_WAVE)
+        for (int r = 0; r < 8; r++) L.ring[r][i] = T[r][i];
+    store_ring(D, g, L);
+}
+
+// copy one slot's state between engines' arrays (same device)
+__global__ __launch_bounds__(64) void k_state_copy(Dev Dd, int gd, Dev Ds, int gs, int ref_semantics)
+{
+    __shared__ WLds L;
+    PS s;
+    load_scalars(Ds, gs, s);
+    load_ring(Ds, gs, L);
+    if (ref_semantics && Ds.geo.game == G_GO) { s.is_end = 0; s.passes_b = 0; s.passes_w = 0; }
+    store_ring(Dd, gd, L);
+    store_scalars(Dd, gd, s);
+}
+
+__global__ void k_begin(Dev D, const int32_t *slots, int n, const int32_t *sides, const int32_t *dflags)
+{
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    int g = slots[q];
+    D.phase[g] = PH_NEED_START; D.side[g] = sides[q]; D.dflag[g] = dflags[q]; D.pdone[g] = 0; D.automode[g] = 0;
+}
+
+__global__ void k_set_pending(Dev D, const int32_t *slots, int n, const int32_t *moves, int side_sel)
+{
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    int g = slots[q];
+    if (side_sel < 0 || side_sel == 0) D.pending[2 * g] = moves[q];
+    if (side_sel < 0 || side_sel == 1) D.pending[2 * g + 1] = moves[q];
+}
+
+__global__ __launch_bounds__(64) void k_choose(Dev D, int g, int side, double u, int32_t *out)
+{
+    __shared__ WLds L;
+    int n = 0;
+    int mv = dev_choose(D, L, 2 * g + side, u, &n);
+    if (lane_id() == 0) out[0] = mv;
+}

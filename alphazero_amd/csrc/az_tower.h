@@ -1,0 +1,21 @@
+// Dual-head residual tower (inference only) - internal interface used by az_engine.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+
+struct Tower;
+
+Tower *tower_create(int H, int W, int O, int num_blocks, int channels, int dtype, int max_batch, std::string &err);
+void tower_destroy(Tower *t);
+size_t tower_blob_floats(const Tower *t);
+// host float32 blob (layout: alphazero_amd/network/model.py) -> device weights in the compute dtype
+int tower_load(Tower *t, const float *host_blob, size_t n_floats, hipStream_t st, std::string &err);
+bool tower_ready(const Tower *t);
+// planes_dev int8 (B,17,H,W); priors_dev (B,O), values_dev (B) float32
+int tower_forward(Tower *t, const int8_t *planes_dev, int B, float *priors_dev, float *values_dev, hipStream_t st,
+                  std::string &err);
+double tower_flops_per_eval(const Tower *t);
+// names/durations of the dominant kernel for the roofline line
+double tower_conv_flops_per_launch(const Tower *t, int B);

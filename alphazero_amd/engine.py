@@ -1,0 +1,243 @@
+"""Python handle on one GPU's batched self-play engine (thin layer over the C ABI)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import AzConfig, AzCounters, AzStateBlob, GAME_IDS, NPLANES
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("az_engine error %d: %s" % (code, msg))
+        self.code = code
+
+
+class IllegalMove(Exception):
+    """Raised by the env shims when the engine reports AZ_ERR_ILLEGAL_MOVE."""
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def game_config_to_engine_kwargs(game_config):
+    """Map a reference game yaml dict (AlphaZero/config/<game>.yaml) to Engine kwargs."""
+    env = game_config.get("env_path", "")
+    name = env.rsplit(".", 1)[-1] if env else str(game_config.get("name", "go"))
+    game = "go" if name.startswith("go") else ("reversi" if name.startswith("reversi") else "mnk")
+    return dict(game=game, board_height=int(game_config["board_height"]), board_width=int(game_config["board_width"]),
+                k=int(game_config.get("k", 0)), transform_types=int(game_config.get("transform_types", 0)),
+                d_alpha=float(game_config.get("d_alpha", 0.03)), d_epsilon=float(game_config.get("d_epsilon", 0.25)))
+
+
+class Engine:
+    def __init__(self, game, board_height, board_width, k=0, n_slots=1, max_playout=0, transform_types=0,
+                 dirichlet_before=30, max_turn=400, d_alpha=0.03, d_epsilon=0.25, tree_edge_cap=0, tree_block_cap=0,
+                 max_depth=0, rng_replay=False, seed=0, record_trajectories=False, num_blocks=0, channels=256,
+                 tower_dtype="bf16", device=0):
+        self._L = _lib.lib()
+        cfg = AzConfig(GAME_IDS[game] if isinstance(game, str) else int(game), board_height, board_width, k, n_slots,
+                       max_playout, transform_types, dirichlet_before, max_turn, d_alpha, d_epsilon, tree_edge_cap,
+                       tree_block_cap, max_depth, int(rng_replay), seed, int(record_trajectories), num_blocks, channels,
+                       {"fp32": 0, "bf16": 1}[tower_dtype] if isinstance(tower_dtype, str) else int(tower_dtype), device)
+        self.cfg = cfg
+        self._h = self._L.az_engine_create(C.byref(cfg))
+        if not self._h:
+            raise EngineError(-2, self._L.az_last_error(None).decode())
+        self.game = game
+        self.H, self.W = board_height, board_width
+        self.NC = board_height * board_width
+        self.O = self.NC + (0 if cfg.game == 2 else 1)
+        self.G = n_slots
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.az_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise EngineError(rc, self._L.az_last_error(self._h).decode())
+        return rc
+
+    # ---- state / rules ---------------------------------------------------
+    def reset(self, slots):
+        s = _i32(slots)
+        self._ck(self._L.az_games_reset(self._h, s.ctypes.data, s.size))
+
+    def state_copy(self, dst_slot, src_engine, src_slot, ref_semantics=True):
+        self._ck(self._L.az_state_copy(self._h, dst_slot, src_engine._h, src_slot, int(ref_semantics)))
+
+    def state_get(self, slot):
+        b = AzStateBlob()
+        self._ck(self._L.az_state_get(self._h, slot, C.byref(b)))
+        return b
+
+    def state_set(self, slot, blob):
+        self._ck(self._L.az_state_set(self._h, slot, C.byref(blob)))
+
+    def board(self, slot):
+        b = self.state_get(slot)
+        return np.frombuffer(b.board, dtype=np.int8, count=self.NC).reshape(self.H, self.W).copy()
+
+    def legal_mask(self, slots):
+        s = _i32(slots)
+        out = np.zeros((s.size, self.O), np.uint8)
+        self._ck(self._L.az_rules_legal_mask(self._h, s.ctypes.data, s.size, out.ctypes.data))
+        return out
+
+    def do_move(self, slots, actions, colors=None):
+        s, a = _i32(slots), _i32(actions)
+        c = _i32(colors) if colors is not None else None
+        status = np.zeros(s.size, np.int32)
+        ended = np.zeros(s.size, np.int32)
+        self._ck(self._L.az_rules_do_move(self._h, s.ctypes.data, s.size, a.ctypes.data,
+                                          c.ctypes.data if c is not None else None, status.ctypes.data, ended.ctypes.data))
+        return status, ended
+
+    def winner(self, slots):
+        s = _i32(slots)
+        out = np.zeros(s.size, np.int32)
+        self._ck(self._L.az_rules_winner(self._h, s.ctypes.data, s.size, out.ctypes.data))
+        return out
+
+    def transform(self, slot, tid):
+        self._ck(self._L.az_state_transform(self._h, slot, tid))
+
+    def features(self, slots, tids=None):
+        s = _i32(slots)
+        t = _i32(tids) if tids is not None else None
+        out = np.zeros((s.size, NPLANES, self.H, self.W), np.int8)
+        self._ck(self._L.az_features(self._h, s.ctypes.data, s.size, t.ctypes.data if t is not None else None, out.ctypes.data))
+        return out
+
+    # ---- search ------------------------------------------------------------
+    def search_begin(self, slots, sides, dirichlet):
+        s, sd, d = _i32(slots), _i32(sides), _i32(dirichlet)
+        self._ck(self._L.az_search_begin(self._h, s.ctypes.data, s.size, sd.ctypes.data, d.ctypes.data))
+
+    def step_select(self):
+        n = C.c_int32(0)
+        self._ck(self._L.az_search_step_select(self._h, C.byref(n)))
+        return n.value
+
+    def leaf_batch(self):
+        planes = np.zeros((self.G, NPLANES, self.H, self.W), np.int8)
+        valid = np.zeros(self.G, np.uint8)
+        self._ck(self._L.az_leaf_batch(self._h, planes.ctypes.data, valid.ctypes.data))
+        return planes, valid
+
+    def step_finish(self, priors=None, values=None):
+        if priors is None:
+            self._ck(self._L.az_search_step_finish(self._h, None, None))
+            return
+        p = np.ascontiguousarray(priors, np.float32)
+        v = np.ascontiguousarray(values, np.float32)
+        assert p.shape == (self.G, self.O) and v.shape == (self.G,)
+        self._ck(self._L.az_search_step_finish(self._h, p.ctypes.data, v.ctypes.data))
+
+    def root_stats(self, slot, side):
+        a = np.zeros(self.O, np.int32); n = np.zeros(self.O, np.int32)
+        w = np.zeros(self.O, np.float32); p = np.zeros(self.O, np.float32)
+        rn = C.c_int32(0)
+        c = self._ck(self._L.az_search_root_stats(self._h, slot, side, a.ctypes.data, n.ctypes.data, w.ctypes.data,
+                                                  p.ctypes.data, C.byref(rn)))
+        return a[:c], n[:c], w[:c], p[:c], rn.value
+
+    def choose(self, slot, side, u):
+        m = C.c_int32(0)
+        self._ck(self._L.az_search_choose(self._h, slot, side, float(u), C.byref(m)))
+        return m.value
+
+    def advance_tree(self, slot, side, move):
+        self._ck(self._L.az_search_advance_tree(self._h, slot, side, int(move)))
+
+    def advance(self, slots, moves):
+        s, m = _i32(slots), _i32(moves)
+        self._ck(self._L.az_search_advance(self._h, s.ctypes.data, s.size, m.ctypes.data))
+
+    def tree_size(self, slot, side):
+        e, b = C.c_int32(0), C.c_int32(0)
+        self._ck(self._L.az_search_tree_size(self._h, slot, side, C.byref(e), C.byref(b)))
+        return e.value, b.value
+
+    # ---- self-play machine ----------------------------------------------------
+    def selfplay_start(self):
+        self._ck(self._L.az_selfplay_start(self._h))
+
+    def selfplay_run(self, n_rounds):
+        self._ck(self._L.az_selfplay_run(self._h, int(n_rounds)))
+
+    def selfplay_select(self):
+        n = C.c_int32(0)
+        self._ck(self._L.az_selfplay_select(self._h, C.byref(n)))
+        return n.value
+
+    def selfplay_finish(self, priors=None, values=None):
+        if priors is None:
+            self._ck(self._L.az_selfplay_finish(self._h, None, None))
+            return
+        p = np.ascontiguousarray(priors, np.float32)
+        v = np.ascontiguousarray(values, np.float32)
+        assert p.shape == (self.G, self.O) and v.shape == (self.G,)
+        self._ck(self._L.az_selfplay_finish(self._h, p.ctypes.data, v.ctypes.data))
+
+    def selfplay_status(self):
+        plies = np.zeros(self.G, np.int32); done = np.zeros(self.G, np.int32)
+        self._ck(self._L.az_selfplay_status(self._h, plies.ctypes.data, done.ctypes.data))
+        return plies, done
+
+    def trajectory_pop(self, slot, restart=False):
+        mp = self._L.az_trajectory_max_plies(self._h)
+        moves = np.zeros(mp, np.int16); visits = np.zeros((mp, self.O), np.int32)
+        w = C.c_int32(0)
+        n = self._ck(self._L.az_trajectory_pop(self._h, slot, moves.ctypes.data, visits.ctypes.data, C.byref(w), int(restart)))
+        return dict(moves=moves[:n].copy(), visits=visits[:n].copy(), winner=w.value)
+
+    # ---- rng ---------------------------------------------------------------------
+    def rng_inject(self, slot, tids=(), etas=(), unis=()):
+        t = np.ascontiguousarray(tids, np.int32); e = np.ascontiguousarray(etas, np.float64)
+        u = np.ascontiguousarray(unis, np.float64)
+        self._ck(self._L.az_rng_inject(self._h, slot, t.ctypes.data, t.size, e.ctypes.data, e.size, u.ctypes.data, u.size))
+
+    def rng_cursor(self, slot):
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._ck(self._L.az_rng_cursor(self._h, slot, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    # ---- tower ---------------------------------------------------------------------
+    def tower_blob_floats(self):
+        return self._L.az_tower_blob_floats(self._h)
+
+    def tower_load(self, blob):
+        b = np.ascontiguousarray(blob, np.float32)
+        self._ck(self._L.az_tower_load_weights(self._h, b.ctypes.data, b.size))
+
+    def tower_forward(self, planes):
+        x = np.ascontiguousarray(planes, np.int8)
+        B = x.shape[0]
+        p = np.zeros((B, self.O), np.float32); v = np.zeros(B, np.float32)
+        self._ck(self._L.az_tower_forward(self._h, x.ctypes.data, B, p.ctypes.data, v.ctypes.data))
+        return p, v
+
+    def tower_flops_per_eval(self):
+        return self._L.az_tower_flops_per_eval(self._h)
+
+    # ---- measurement -----------------------------------------------------------------
+    def counters(self):
+        c = AzCounters()
+        self._ck(self._L.az_counters_get(self._h, C.byref(c)))
+        return {k: getattr(c, k) for k, _ in AzCounters._fields_}
+
+    def counters_reset(self):
+        self._ck(self._L.az_counters_reset(self._h))
+
+    def sync(self):
+        self._ck(self._L.az_sync(self._h))

@@ -1,0 +1,192 @@
+/*
+ * az_engine.h - C ABI of the MI355X batched self-play engine.
+ *
+ * The reference has no FFI: its plug-in boundary is three Python modules
+ * chosen by YAML keys (env_path / state_converter_path / gameplay_path,
+ * AlphaZero/config/go.yaml:3-6) plus the evaluator/search/player contracts.
+ * The Python modules in alphazero_amd/ keep those contracts and bind the
+ * entry points below through ctypes; each entry point names the reference
+ * interface it stands in for.
+ *
+ * Conventions: opaque handle, int status (0 = ok, <0 = AZ_ERR_*),
+ * caller-owned buffers (host pointers unless the name ends in _dev), no
+ * exceptions across the boundary, one host thread per handle (one handle per
+ * GPU).  Actions are flat indices x*W + y; PASS is H*W.  A "slot" is one game
+ * (state + the two search trees of its two players); a "side" is 0 for
+ * player_1 (moves first) and 1 for player_2.
+ */
+#ifndef AZ_ENGINE_H
+#define AZ_ENGINE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZ_GO 0
+#define AZ_REVERSI 1
+#define AZ_MNK 2
+
+#define AZ_OK 0
+#define AZ_ERR_ARG (-1)
+#define AZ_ERR_HIP (-2)
+#define AZ_ERR_ILLEGAL_MOVE (-3)   /* the module-level IllegalMove of the env modules */
+#define AZ_ERR_TREE_FULL (-4)      /* a tree arena overflowed (raise tree_*_cap) */
+#define AZ_ERR_RNG_UNDERFLOW (-5)  /* a replay stream ran dry */
+#define AZ_ERR_DEPTH (-6)          /* a playout went deeper than max_depth */
+#define AZ_ERR_STATE (-7)          /* call not valid in the handle's current phase */
+#define AZ_ERR_NO_WEIGHTS (-8)
+
+#define AZ_MAX_CELLS 361
+#define AZ_MAX_ACTIONS 362
+#define AZ_CELL_PAD 384            /* per-board stride in bytes */
+#define AZ_NPLANES 17              /* history_step*planes_per_step + additional_planes */
+
+#define AZ_TOWER_FP32 0
+#define AZ_TOWER_BF16 1
+
+typedef struct az_engine az_engine;
+
+typedef struct az_config {
+    int32_t game;              /* AZ_GO / AZ_REVERSI / AZ_MNK  (config key env_path) */
+    int32_t board_height, board_width, k;
+    int32_t n_slots;           /* concurrent games on this GPU */
+    int32_t max_playout;       /* ext_config['player']['max_playout'] */
+    int32_t transform_types;   /* 0/1 = off, 8 = dihedral (square boards) */
+    int32_t dirichlet_before;  /* noise while turns <= this */
+    int32_t max_turn;          /* game stops when turns > this */
+    double d_alpha, d_epsilon;
+    int32_t tree_edge_cap;     /* edges per tree; 0 = 3*(max_playout+1)*O */
+    int32_t tree_block_cap;    /* expanded nodes per tree; 0 = 8*(max_playout+1) */
+    int32_t max_depth;         /* playout path bound; 0 = 1024 */
+    int32_t rng_replay;        /* 1: draws come from az_rng_inject streams; 0: device generator */
+    uint64_t seed;
+    int32_t record_trajectories; /* keep per-ply moves + visit counts for az_trajectory_pop */
+    /* tower (AlphaZero/network/model.py:39-88) */
+    int32_t num_blocks;        /* residual blocks; 0 = no tower (priors must be injected) */
+    int32_t channels;          /* 256 in the reference (model.py:47,55-56) */
+    int32_t tower_dtype;       /* AZ_TOWER_FP32 / AZ_TOWER_BF16 */
+    int32_t device;            /* HIP device ordinal */
+} az_config;
+
+/* Fixed-layout copy of one game state (attributes of env/*.py GameState). */
+typedef struct az_state_blob {
+    int8_t board[AZ_CELL_PAD];
+    int8_t history[7][AZ_CELL_PAD];   /* board_history, oldest first */
+    int32_t current_player, ko, turns, n_history, last1, last2;
+    int32_t is_end_of_game, winner, winner_set;
+    int32_t passes_black, passes_white;
+    int32_t num_black_prisoners, num_white_prisoners, stones_played;
+} az_state_blob;
+
+typedef struct az_counters {
+    uint64_t steps;            /* select/evaluate/backup rounds */
+    uint64_t evals;            /* leaf evaluations consumed (= MCTS sims incl. root expansions) */
+    uint64_t moves;            /* plies played by the self-play machine */
+    uint64_t games_finished;
+    uint64_t levels;           /* tree levels descended */
+    uint64_t children_scanned; /* edges read by select */
+    uint64_t edges_created;    /* edges written by expand */
+    uint64_t rule_moves;       /* do_move replays inside playouts */
+    double tower_ms;           /* HIP-event time of all tower forwards since reset */
+    double select_ms, finish_ms;
+    uint64_t tower_calls;
+    uint64_t tower_evals;      /* rows pushed through the tower */
+} az_counters;
+
+/* ---- lifetime ------------------------------------------------------- */
+/* Replaces constructing GameState/Player/Game objects one process per game
+ * (AlphaZero/train/parallel/selfplay.py:71-108). */
+az_engine *az_engine_create(const az_config *cfg);
+void az_engine_destroy(az_engine *h);
+const char *az_last_error(az_engine *h);       /* h may be NULL (creation errors) */
+int az_engine_dims(az_engine *h, int32_t *n_slots, int32_t *cells, int32_t *actions);
+
+/* ---- game state (env/go.py, env/reversi.py, env/mnk.py GameState) ----- */
+/* GameState(): initial position, both trees cleared, search idle */
+int az_games_reset(az_engine *h, const int32_t *slots, int32_t n);
+/* GameState.copy(): ref_semantics=1 applies the reference's copy() quirks
+ * (Go drops pass counters and the end flag, env/go.py:242-272) */
+int az_state_copy(az_engine *dst, int32_t dst_slot, az_engine *src, int32_t src_slot, int32_t ref_semantics);
+int az_state_get(az_engine *h, int32_t slot, az_state_blob *out);
+int az_state_set(az_engine *h, int32_t slot, const az_state_blob *in);
+/* GameState.is_legal for every action, tensor-index order, PASS last */
+int az_rules_legal_mask(az_engine *h, const int32_t *slots, int32_t n, uint8_t *mask /* n*O */);
+/* GameState.do_move(action, color): colors may be NULL (current player);
+ * status[i] = AZ_OK or AZ_ERR_ILLEGAL_MOVE (state untouched); ended[i] = return value */
+int az_rules_do_move(az_engine *h, const int32_t *slots, int32_t n, const int32_t *actions,
+                     const int32_t *colors, int32_t *status, int32_t *ended);
+/* GameState.get_winner(): +1 / -1 / 0, 2 = None (mnk before the end) */
+int az_rules_winner(az_engine *h, const int32_t *slots, int32_t n, int32_t *winner);
+/* GameState.transform(id) on board + history (env/go.py:573-594) */
+int az_state_transform(az_engine *h, int32_t slot, int32_t transform_id);
+
+/* ---- features (processing/state_converter.py:48-82) ------------------- */
+/* StateTensorConverter.state_to_tensor on copy().transform(id): int8 (n,17,H,W) */
+int az_features(az_engine *h, const int32_t *slots, int32_t n, const int32_t *transform_ids, int8_t *planes);
+
+/* ---- search (search/mcts.py MCTSearch; player/mcts_player.py Player) --- */
+/* MCTSearch._calc_move(state, dirichlet) on tree `side` of each slot: arms the search;
+ * it then advances one leaf per az_search_step_* round. */
+int az_search_begin(az_engine *h, const int32_t *slots, int32_t n, const int32_t *sides, const int32_t *dirichlet);
+/* One descent per searching tree (MCTSearch._playout down to the leaf, mcts.py:173-217);
+ * n_leaves = trees that need an evaluation this round (0 = all searches finished). */
+int az_search_step_select(az_engine *h, int32_t *n_leaves);
+/* The evaluator's view of this round's leaves (NNEvaluator.eval input,
+ * evaluator/nn_eval_parallel.py:85): planes int8 (n_slots,17,H,W), valid[n_slots] */
+int az_leaf_batch(az_engine *h, int8_t *planes, uint8_t *valid);
+/* expand / terminal handling / backup (mcts.py:217-232,196-202,283-291).
+ * priors (n_slots,O) and values (n_slots) float32 host arrays, in the evaluator's
+ * (transformed) index order; both NULL = run the tower on the leaf batch. */
+int az_search_step_finish(az_engine *h, const float *priors, const float *values);
+/* root children in insertion order (MCTreeNode._children of _root): returns count */
+int az_search_root_stats(az_engine *h, int32_t slot, int32_t side, int32_t *actions, int32_t *visits,
+                         float *total_value, float *prior, int32_t *root_visits);
+/* math_helper.weighted_random_choice over _get_search_probs with uniform draw u */
+int az_search_choose(az_engine *h, int32_t slot, int32_t side, double u, int32_t *move);
+/* MCTSearch.update_with_move for one tree / Player.ack for both trees of a slot */
+int az_search_advance_tree(az_engine *h, int32_t slot, int32_t side, int32_t move);
+int az_search_advance(az_engine *h, const int32_t *slots, int32_t n, const int32_t *moves);
+/* nodes (edges) and expanded nodes currently held by a tree */
+int az_search_tree_size(az_engine *h, int32_t slot, int32_t side, int32_t *edges, int32_t *blocks);
+
+/* ---- self-play machine (game/gameplay.py Game.start over all slots) ---- */
+int az_selfplay_start(az_engine *h);            /* reset every slot and arm player_1's first search */
+/* n rounds of select -> tower -> finish -> (move, re-root, next search) */
+int az_selfplay_run(az_engine *h, int32_t n_rounds);
+/* injected-evaluator variant of one round: select, then the caller evaluates
+ * az_leaf_batch, then finish(priors, values) which also plays due moves */
+int az_selfplay_select(az_engine *h, int32_t *n_leaves);
+int az_selfplay_finish(az_engine *h, const float *priors, const float *values);
+/* per-slot progress: plies played, 1 if the game is over and waits for az_trajectory_pop */
+int az_selfplay_status(az_engine *h, int32_t *plies /* n_slots */, int32_t *done /* n_slots */);
+/* Game.get_history raw material for a finished slot: moves[n_plies], visit counts
+ * (n_plies,O) scattered by action, winner.  restart=1 re-arms the slot with a new game.
+ * Returns n_plies, or AZ_ERR_STATE if the slot's game is not finished. */
+int az_trajectory_pop(az_engine *h, int32_t slot, int16_t *moves, int32_t *visits, int32_t *winner, int32_t restart);
+int az_trajectory_max_plies(az_engine *h);
+
+/* ---- RNG (numpy.random.randint / random.gammavariate / random.choices) - */
+/* replay streams for one slot: transform ids, gamma draws, move-choice uniforms */
+int az_rng_inject(az_engine *h, int32_t slot, const int32_t *tids, int64_t n_tids, const double *etas,
+                  int64_t n_etas, const double *unis, int64_t n_unis);
+int az_rng_cursor(az_engine *h, int32_t slot, int64_t *i_tids, int64_t *i_etas, int64_t *i_unis);
+
+/* ---- tower (network/model.py, network/main.py:111-127 Network.response) - */
+size_t az_tower_blob_floats(az_engine *h);      /* float32 count of the folded-weight blob */
+/* folded float32 weights, layout documented in alphazero_amd/network/model.py */
+int az_tower_load_weights(az_engine *h, const float *blob, size_t n_floats);
+/* x int8 (B,17,H,W) host; out_p (B,O), out_v (B) float32 host */
+int az_tower_forward(az_engine *h, const int8_t *planes, int32_t B, float *out_p, float *out_v);
+double az_tower_flops_per_eval(az_engine *h);
+
+/* ---- measurement ------------------------------------------------------ */
+int az_counters_get(az_engine *h, az_counters *out);
+int az_counters_reset(az_engine *h);
+int az_sync(az_engine *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,179 @@
+"""GPU parity: PUCT select / expand / backup / re-root / move choice of the HIP engine against
+fixtures recorded from the reference's MCTSearch with injected float32 priors and values and
+replayed RNG draws.  Visit counts, W and P are compared bit for bit, through the C ABI."""
+import numpy as np
+import pytest
+
+from oracle import oracle as oz
+from oracle.fake_eval import fake_eval_planes
+from tests.helpers import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine_for(g, n_slots=1, record=False, **kw):
+    from alphazero_amd.engine import Engine
+    return Engine(str(g["game"]), int(g["H"]), int(g["W"]), int(g["k"]), n_slots=n_slots,
+                  max_playout=int(g["max_playout"]), transform_types=int(g["transform_types"]),
+                  dirichlet_before=int(g["dirichlet_before"]), max_turn=int(g["max_turn"]),
+                  d_alpha=float(g["d_alpha"]), d_epsilon=float(g["d_epsilon"]), rng_replay=True,
+                  record_trajectories=record, **kw)
+
+
+def _run_search(eng):
+    O = eng.O
+    rounds = 0
+    while True:
+        n = eng.step_select()
+        if n == 0:
+            break
+        planes, valid = eng.leaf_batch()
+        pri, v = fake_eval_planes(planes, O)
+        eng.step_finish(pri, v)
+        rounds += 1
+    return rounds
+
+
+@pytest.mark.parametrize("name", golden_names("search_"))
+def test_search_trace_manual_api(name):
+    g = load_golden(name)
+    eng = _engine_for(g)
+    eng.rng_inject(0, g["tids"], g["etas"], g["unis"])
+    side, evals, ui = 0, 0, 0
+    for ply in range(len(g["moves"])):
+        assert np.array_equal(eng.board(0), g["boards"][ply]), ply
+        st = eng.state_get(0)
+        dirichlet = st.turns <= int(g["dirichlet_before"])
+        eng.search_begin([0], [side], [int(dirichlet)])
+        evals += _run_search(eng)
+        a, n, w, p, rootN = eng.root_stats(0, side)
+        nc = int(g["n_children"][ply])
+        assert len(a) == nc, (ply, len(a), nc)
+        assert np.array_equal(a, g["acts"][ply][:nc]), ply
+        assert np.array_equal(n, g["N"][ply][:nc]), ply
+        assert np.array_equal(w.view(np.uint32), g["Wv"][ply][:nc].view(np.uint32)), ply
+        assert np.array_equal(p.view(np.uint32), g["P"][ply][:nc].view(np.uint32)), ply
+        assert rootN == g["rootN"][ply]
+        assert evals == g["cum_evals"][ply]
+        it, ie, iu = eng.rng_cursor(0)
+        assert it == g["cum_tids"][ply] and ie == g["cum_etas"][ply]
+        mv = eng.choose(0, side, float(g["unis"][ui])); ui += 1
+        assert mv == g["moves"][ply], ply
+        status, _ = eng.do_move([0], [mv])
+        assert status[0] == 0
+        eng.advance([0], [mv])
+        side ^= 1
+    assert np.array_equal(eng.board(0), g["final_board"])
+    eng.close()
+
+
+def _selfplay_injected(eng):
+    while True:
+        n = eng.selfplay_select()
+        if n == 0:
+            break
+        planes, _ = eng.leaf_batch()
+        pri, v = fake_eval_planes(planes, eng.O)
+        eng.selfplay_finish(pri, v)
+
+
+@pytest.mark.parametrize("name", ["search_ttt_game", "search_reversi_game", "search_go5_game"])
+def test_selfplay_machine_full_game(name):
+    """Game.start + get_history raw material from the device-side self-play machine, 3 slots
+    fed the same draws must all reproduce the reference's game."""
+    g = load_golden(name)
+    if int(g["ply_limit"]) <= len(g["moves"]):
+        pytest.skip("fixture is not a complete game")
+    G = 3
+    eng = _engine_for(g, n_slots=G, record=True)
+    for s in range(G):
+        eng.rng_inject(s, g["tids"], g["etas"], g["unis"])
+    eng.selfplay_start()
+    _selfplay_injected(eng)
+    plies, done = eng.selfplay_status()
+    assert np.all(done == 1) and np.all(plies == len(g["moves"]))
+    O = eng.O
+    for s in range(G):
+        tr = eng.trajectory_pop(s)
+        assert np.array_equal(tr["moves"], g["moves"])
+        assert tr["winner"] == g["winner"]
+        for ply in range(len(g["moves"])):
+            nc = int(g["n_children"][ply])
+            exp = np.zeros(O, np.int32)
+            exp[g["acts"][ply][:nc]] = g["N"][ply][:nc]
+            assert np.array_equal(tr["visits"][ply], exp), ply
+        if "hist_probs" in g:
+            probs = tr["visits"].astype(np.float64) / tr["visits"].sum(axis=1, keepdims=True)
+            assert np.array_equal(probs, g["hist_probs"])
+    assert np.array_equal(eng.board(0), g["final_board"])
+    c = eng.counters()
+    assert c["evals"] == G * int(g["total_evals"]) and c["moves"] == G * len(g["moves"])
+    eng.close()
+
+
+@pytest.mark.parametrize("game,H,W,k,tt,P,db,mt,G", [
+    ("mnk", 3, 3, 3, 0, 100, 30, 400, 16),
+    ("go", 5, 5, 0, 8, 40, 6, 30, 16),
+    ("reversi", 6, 6, 0, 8, 24, 30, 400, 8),
+    ("go", 9, 9, 0, 8, 48, 30, 12, 8),
+    ("mnk", 7, 7, 4, 8, 30, 30, 400, 8),
+])
+def test_selfplay_machine_vs_oracle(game, H, W, k, tt, P, db, mt, G):
+    """G different seeded games in one engine vs the C oracle's oz_play_game, full trajectories."""
+    from alphazero_amd.engine import Engine
+    rng = np.random.RandomState(1234 + H * 7 + P)
+    eng = Engine(game, H, W, k, n_slots=G, max_playout=P, transform_types=tt, dirichlet_before=db, max_turn=mt,
+                 rng_replay=True, record_trajectories=True)
+    O = eng.O
+    streams = []
+    nmax = (mt + 2) * (P + 1)
+    for s in range(G):
+        tids = rng.randint(0, 8, size=nmax).astype(np.int32)
+        etas = rng.gamma(0.03, 1.0, size=(mt + 2) * O)
+        unis = rng.rand(mt + 2)
+        streams.append((tids, etas, unis))
+        eng.rng_inject(s, tids, etas, unis)
+    eng.selfplay_start()
+    _selfplay_injected(eng)
+    plies, done = eng.selfplay_status()
+    assert np.all(done == 1)
+    for s in range(G):
+        tids, etas, unis = streams[s]
+        ref = oz.play_game(game, H, W, k, tt, P, db, mt, oz.fn_ptr("oz_fake_eval"), oz.Rng(tids, etas, unis))
+        tr = eng.trajectory_pop(s)
+        assert np.array_equal(tr["moves"], ref["moves"]), s
+        assert np.array_equal(tr["visits"], ref["visits"]), s
+        assert tr["winner"] == ref["winner"], s
+    eng.close()
+
+
+def test_tree_arena_overflow_is_reported():
+    from alphazero_amd.engine import Engine, EngineError
+    eng = Engine("go", 5, 5, n_slots=1, max_playout=50, transform_types=0, tree_edge_cap=60, tree_block_cap=4)
+    eng.search_begin([0], [0], [0])
+    with pytest.raises(EngineError) as ei:
+        _run_search(eng)
+    assert ei.value.code == -4
+    eng.close()
+
+
+def test_reroot_keeps_subtree_and_compacts():
+    """update_with_move: the kept child's statistics survive, the arena shrinks, a move that is
+    not a child gives a fresh root (search/mcts.py:336-346)."""
+    from alphazero_amd.engine import Engine
+    eng = Engine("go", 5, 5, n_slots=1, max_playout=120, transform_types=0)
+    eng.search_begin([0], [0], [0])
+    _run_search(eng)
+    a, n, w, p, rootN = eng.root_stats(0, 0)
+    assert rootN == 121 and n.sum() == 120
+    e0, b0 = eng.tree_size(0, 0)
+    best = int(np.argmax(n))
+    eng.do_move([0], [int(a[best])])
+    eng.advance_tree(0, 0, int(a[best]))
+    a2, n2, w2, p2, rootN2 = eng.root_stats(0, 0)
+    assert rootN2 == n[best] and n2.sum() == n[best] - 1
+    e1, b1 = eng.tree_size(0, 0)
+    assert e1 < e0 and b1 < b0 and b1 >= 1
+    eng.advance_tree(0, 0, 25 if 25 not in a2 else int(a2[0]))
+    eng.advance_tree(0, 0, 0)  # whatever it was, walk on: unknown children reset the tree
+    eng.close()
