@@ -46,6 +46,7 @@ class AzCounters(C.Structure):
         ("rule_moves", C.c_uint64),
         ("tower_ms", C.c_double), ("select_ms", C.c_double), ("finish_ms", C.c_double),
         ("tower_calls", C.c_uint64), ("tower_evals", C.c_uint64),
+        ("conv_ms", C.c_double), ("conv_launches", C.c_uint64), ("conv_flops_per_launch", C.c_double),
     ]
 
 
@@ -88,6 +89,7 @@ SIGNATURES = {
     "az_tower_load_weights": (_I, [_P, _P, C.c_size_t]),
     "az_tower_forward": (_I, [_P, _P, _I, _P, _P]),
     "az_tower_flops_per_eval": (C.c_double, [_P]),
+    "az_tower_profile": (_I, [_P, _I]),
     "az_counters_get": (_I, [_P, C.POINTER(AzCounters)]),
     "az_counters_reset": (_I, [_P]),
     "az_sync": (_I, [_P]),

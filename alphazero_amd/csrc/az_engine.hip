@@ -569,6 +569,7 @@ extern "C" int az_selfplay_run(az_engine *h, int32_t n_rounds)
         hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
         hipEventElapsedTime(&c, h->ev[2], h->ev[3]);
         h->select_ms += a; h->tower_ms += b; h->finish_ms += c;
+        tower_collect_profile(h->tower);
         h->steps++;
     }
     HIPCHK(hipGetLastError());
@@ -721,6 +722,15 @@ extern "C" int az_tower_forward(az_engine *h, const int8_t *planes, int32_t B, f
     return AZ_OK;
 }
 
+extern "C" int az_tower_profile(az_engine *h, int32_t on)
+{
+    if (!h || !h->tower) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    tower_set_profile(h->tower, on != 0);
+    return AZ_OK;
+}
+
 extern "C" double az_tower_flops_per_eval(az_engine *h) { return (h && h->tower) ? tower_flops_per_eval(h->tower) : 0.0; }
 
 // ---- measurement -----------------------------------------------------------------
@@ -737,6 +747,13 @@ extern "C" int az_counters_get(az_engine *h, az_counters *out)
     out->rule_moves = c[C_RULEMOVES];
     out->tower_ms = h->tower_ms; out->select_ms = h->select_ms; out->finish_ms = h->finish_ms;
     out->tower_calls = h->tower_calls; out->tower_evals = h->tower_evals;
+    out->conv_ms = 0; out->conv_launches = 0; out->conv_flops_per_launch = 0;
+    if (h->tower) {
+        unsigned long long n = 0;
+        tower_profile_read(h->tower, &out->conv_ms, &n, false);
+        out->conv_launches = n;
+        out->conv_flops_per_launch = tower_conv_flops_per_launch(h->tower, h->D.G);
+    }
     return AZ_OK;
 }
 
@@ -748,6 +765,7 @@ extern "C" int az_counters_reset(az_engine *h)
     HIPCHK(hipMemset(h->D.ctr, 0, sizeof(unsigned long long) * C_N));
     h->tower_ms = h->select_ms = h->finish_ms = 0;
     h->tower_calls = h->tower_evals = h->steps = 0;
+    if (h->tower) { double a; unsigned long long b; tower_profile_read(h->tower, &a, &b, true); }
     return AZ_OK;
 }
 

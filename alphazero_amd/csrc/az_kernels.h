@@ -415,7 +415,7 @@ __global__ __launch_bounds__(64) void k_reroot(Dev D)
             int c = c0 + lane;
             int hit = (c < n) && (D.eAct[tb + start + c] == mv);
             unsigned long long bal = __ballot(hit);
-            if (bal) { found = start + __ffsll((long long)bal) - 1; break; }
+            if (bal) { found = start + c0 + __ffsll((long long)bal) - 1; break; }
         }
     }
     if (found < 0) {  // MCTreeNode(None, 1.0)

@@ -19,3 +19,7 @@ int tower_forward(Tower *t, const int8_t *planes_dev, int B, float *priors_dev, 
 double tower_flops_per_eval(const Tower *t);
 // names/durations of the dominant kernel for the roofline line
 double tower_conv_flops_per_launch(const Tower *t, int B);
+// per-launch HIP-event timing of the residual-tower 3x3 convolutions
+void tower_set_profile(Tower *t, bool on);
+void tower_collect_profile(Tower *t);
+void tower_profile_read(Tower *t, double *conv_ms, unsigned long long *launches, bool reset);

@@ -32,6 +32,12 @@ struct Tower {
     float *w_v1, *b_v1, *w_v2, *b_v2;  // [HW][256], [256], [256], [1]
     void *X0, *X, *T, *Y;           // activations
     float *hp, *hv;                 // [maxB][2*HW], [maxB][HW]
+    // per-launch timing of the residual-tower convolutions (HIP events on the launch stream)
+    bool profile;
+    std::vector<hipEvent_t> evs;    // 2 per conv launch of one forward
+    int evs_used;
+    double conv_ms;
+    unsigned long long conv_launches;
 };
 
 __device__ __forceinline__ bf16_t f2bf(float f)
@@ -340,6 +346,7 @@ Tower *tower_create(int H, int W, int O, int num_blocks, int channels, int dtype
     Tower *t = new Tower();
     t->H = H; t->W = W; t->HW = H * W; t->PP = (H + 2) * (W + 2); t->O = O; t->NB = num_blocks; t->C = channels;
     t->dtype = dtype; t->maxB = max_batch; t->ready = false;
+    t->profile = false; t->evs_used = 0; t->conv_ms = 0; t->conv_launches = 0;
     const size_t C = channels, HW = t->HW;
     t->blob_floats = C * 9 * 17 + C + (size_t)num_blocks * 2 * (C * 9 * C + C) + 3 * C + 3 + 2 * HW * O + O + HW * 256 + 256 + 256 + 1;
     const size_t es = dtype == 1 ? 2 : 4;
@@ -364,6 +371,7 @@ void tower_destroy(Tower *t)
 {
     if (!t) return;
     for (void *p : t->allocs) hipFree(p);
+    for (hipEvent_t e : t->evs) hipEventDestroy(e);
     delete t;
 }
 
@@ -458,8 +466,11 @@ static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float
     for (int l = 0; l < t->NB; l++) {
         const T *w1 = (const T *)t->w_conv + (size_t)(2 * l) * C * 9 * C;
         const T *w2 = (const T *)t->w_conv + (size_t)(2 * l + 1) * C * 9 * C;
+        if (t->profile) hipEventRecord(t->evs[t->evs_used++], st);
         launch_conv<T>(t, X, w1, t->b_conv + (size_t)(2 * l) * C, (const T *)nullptr, Tm, B, (int)C, st);
+        if (t->profile) { hipEventRecord(t->evs[t->evs_used++], st); hipEventRecord(t->evs[t->evs_used++], st); }
         launch_conv<T>(t, Tm, w2, t->b_conv + (size_t)(2 * l + 1) * C, X, Y, B, (int)C, st);
+        if (t->profile) hipEventRecord(t->evs[t->evs_used++], st);
         T *tmp = X; X = Y; Y = tmp;
     }
     hipLaunchKernelGGL((k_head_conv<T>), dim3(B), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, t->hp, t->hv, t->HW, t->W,
@@ -473,8 +484,34 @@ int tower_forward(Tower *t, const int8_t *planes_dev, int B, float *priors_dev, 
 {
     if (!t->ready) { err = "weights not loaded"; return -1; }
     if (B < 1 || B > t->maxB) { err = "batch exceeds the tower's activation buffers"; return -1; }
+    t->evs_used = 0;
     int rc = t->dtype == 1 ? forward_t<bf16_t>(t, planes_dev, B, priors_dev, values_dev, st)
                            : forward_t<float>(t, planes_dev, B, priors_dev, values_dev, st);
     if (rc) err = std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError());
     return rc;
+}
+
+void tower_set_profile(Tower *t, bool on)
+{
+    t->profile = on;
+    if (on && t->evs.empty()) {
+        t->evs.resize((size_t)4 * t->NB);
+        for (auto &e : t->evs) hipEventCreate(&e);
+    }
+}
+
+// call after the launch stream has been synchronised: folds the last forward's event pairs
+void tower_collect_profile(Tower *t)
+{
+    for (int i = 0; i + 1 < t->evs_used; i += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t->evs[i], t->evs[i + 1]) == hipSuccess) { t->conv_ms += ms; t->conv_launches++; }
+    }
+    t->evs_used = 0;
+}
+
+void tower_profile_read(Tower *t, double *conv_ms, unsigned long long *launches, bool reset)
+{
+    *conv_ms = t->conv_ms; *launches = t->conv_launches;
+    if (reset) { t->conv_ms = 0; t->conv_launches = 0; }
 }

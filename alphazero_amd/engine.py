@@ -227,6 +227,9 @@ class Engine:
         self._ck(self._L.az_tower_forward(self._h, x.ctypes.data, B, p.ctypes.data, v.ctypes.data))
         return p, v
 
+    def tower_profile(self, on=True):
+        self._ck(self._L.az_tower_profile(self._h, int(on)))
+
     def tower_flops_per_eval(self):
         return self._L.az_tower_flops_per_eval(self._h)
 

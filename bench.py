@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Self-play throughput of the HIP engine on the headline configuration:
+Go 19x19, 800 sims/move, 20-block 256-channel dual-head ResNet (bf16 MFMA tower), games sharded
+over the GPUs of one node with the weights broadcast over RCCL.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one round of the hot path over every game slot of a GPU: PUCT select (rule replay down to
+one leaf per game) -> feature planes -> tower forward over the leaf batch -> expand/backup ->
+(when a search is complete) move choice, real move, re-root of both trees.  One step therefore
+consumes one network evaluation (= one MCTS simulation) per game.  Inputs are synthetic: seeded
+glorot-uniform weights, games start from the empty board, device RNG seed 0; everything is resident
+in HBM before the timed region.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_TFLOPS_BF16 = 2500.0  # dense bf16 MFMA peak of one MI355X, TFLOP/s
+
+
+def cpu_baseline(H, num_blocks, channels, sims, budget_s=20.0):
+    """The CPU oracle (C port of the reference's rules/search) driving an fp32 PyTorch-CPU restatement of
+    the network, one leaf per evaluation as the reference's per-game search sees it; bounded sample."""
+    import numpy as np
+    import torch
+    from alphazero_amd.network.model import random_net
+    from oracle import oracle as oz
+    from oracle import tower_ref
+
+    O = H * H + 1
+    net = random_net(H, H, O, num_blocks, channels, seed=0)
+    sd = net.state_dict()
+    cores = torch.get_num_threads()
+    n_eval = [0]
+
+    def ev(planes, O_):
+        n_eval[0] += 1
+        x = torch.from_numpy(np.ascontiguousarray(planes)).float()[None]
+        p, v = tower_ref.forward(sd, x, num_blocks)
+        return p[0].numpy(), float(v[0])
+
+    cb = oz.make_eval(ev)
+    st = oz.State("go", H, H)
+    tree = oz.Tree(O, 8)
+    rng = oz.Rng(seed=1)
+    # calibrate with a few playouts, then size the sample to the budget
+    t0 = time.perf_counter()
+    tree.search(st, 4, True, cb, rng)
+    per = (time.perf_counter() - t0) / max(n_eval[0], 1)
+    n = int(max(8, min(sims, budget_s / max(per, 1e-6))))
+    tree = oz.Tree(O, 8)
+    n_eval[0] = 0
+    t0 = time.perf_counter()
+    tree.search(st, n, True, cb, rng)
+    dt = time.perf_counter() - t0
+    sims_per_s = n_eval[0] / dt
+    return {
+        "value": sims_per_s / (sims + 1), "unit": "moves/s", "sims_per_sec": sims_per_s, "cores": cores, "kind": "port",
+        "sample": "first %d simulations of one Go %dx%d game's first search (%d-block %d-ch fp32 net on CPU, "
+                  "one leaf per evaluation); moves/s = sims/s / %d" % (n_eval[0], H, H, num_blocks, channels, sims + 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--games", type=int, default=1024, help="concurrent games per GPU")
+    ap.add_argument("--board", type=int, default=19)
+    ap.add_argument("--sims", type=int, default=800)
+    ap.add_argument("--blocks", type=int, default=20, help="residual blocks after the stem")
+    ap.add_argument("--channels", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.network.model import fold_to_blob, random_net
+    from alphazero_amd import parallel
+
+    H = args.board
+    O = H * H + 1
+    eng = Engine("go", H, H, n_slots=args.games, max_playout=args.sims, transform_types=8, dirichlet_before=30,
+                 max_turn=400, d_alpha=0.03, d_epsilon=0.25, seed=1000 + rank, record_trajectories=True,
+                 num_blocks=args.blocks, channels=args.channels, tower_dtype=args.dtype, device=local_rank)
+    # weights: rank 0 builds them, every rank receives them over RCCL (model update path)
+    blob = None
+    if rank == 0:
+        blob = fold_to_blob(random_net(H, H, O, args.blocks, args.channels, seed=0))
+    blob = parallel.broadcast_weights(blob, eng.tower_blob_floats(), dist, torch.device("cuda", local_rank))
+    eng.tower_load(blob)
+    eng.selfplay_start()
+    eng.tower_profile(True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.sync()
+
+    eng.selfplay_run(args.warmup)
+    eng.counters_reset()
+    barrier()
+    t0 = time.perf_counter()
+    eng.selfplay_run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    c = eng.counters()
+    evals = torch.tensor([float(c["evals"]), float(c["moves"])], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(evals, op=dist.ReduceOp.SUM)
+    total_evals, total_moves = float(evals[0].item()), float(evals[1].item())
+    sims_per_s = total_evals / dt
+    evals_per_move = args.sims + 1  # a search costs max_playout evaluations, +1 when its root is still a leaf
+    moves_per_s = sims_per_s / evals_per_move
+
+    if rank == 0:
+        conv_ms = c["conv_ms"] / max(c["conv_launches"], 1)
+        achieved = c["conv_flops_per_launch"] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        out = {
+            "metric": "self-play moves/sec + MCTS sims/sec (node), Go 19x19 800 sims, 1/2/4/8 GPUs",
+            "value": moves_per_s, "unit": "moves/s", "sims_per_sec": sims_per_s,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {
+                "workload": "Go %dx%d self-play, %d sims/move, stem + %d residual blocks x %d ch dual-head ResNet, "
+                            "%d concurrent games per GPU, dihedral transforms on, Dirichlet noise on the first 31 plies"
+                            % (H, H, args.sims, args.blocks, args.channels, args.games),
+                "games_per_gpu": args.games, "sims_per_move": args.sims, "evals_per_move_used": evals_per_move,
+                "residual_blocks": args.blocks, "channels": args.channels, "parallelism": "games sharded, dp%d" % world,
+                "tower_gflop_per_eval": eng.tower_flops_per_eval() / 1e9,
+            },
+            "moves_completed_in_timed_region": total_moves,
+            "phase_ms_per_step": {"select": c["select_ms"] / args.steps, "tower": c["tower_ms"] / args.steps,
+                                  "finish_move_reroot": c["finish_ms"] / args.steps},
+            "tree_stats_per_sim": {"levels": c["levels"] / max(c["evals"], 1), "children_scanned": c["children_scanned"] / max(c["evals"], 1)},
+            "roofline": {
+                "bound": "mfma", "kernel": "k_conv3x3_bf16<64> (3x3 256->256 implicit GEMM)",
+                "achieved": achieved, "peak": HBM_PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
+                "frac": achieved / HBM_PEAK_TFLOPS_BF16, "traffic": None,
+                "avg_launch_ms": conv_ms, "launches": c["conv_launches"], "flops_per_launch": c["conv_flops_per_launch"],
+            },
+            "tower_tflops_end_to_end": (c["tower_evals"] * eng.tower_flops_per_eval()) / (c["tower_ms"] * 1e-3) / 1e12 if c["tower_ms"] > 0 else 0.0,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(H, args.blocks, args.channels, args.sims)
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

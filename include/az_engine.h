@@ -93,6 +93,9 @@ typedef struct az_counters {
     double select_ms, finish_ms;
     uint64_t tower_calls;
     uint64_t tower_evals;      /* rows pushed through the tower */
+    double conv_ms;            /* HIP-event time of the residual-tower 3x3 conv launches (az_tower_profile on) */
+    uint64_t conv_launches;
+    double conv_flops_per_launch; /* 2 * n_slots * H*W * 9 * C^2 */
 } az_counters;
 
 /* ---- lifetime ------------------------------------------------------- */
@@ -180,6 +183,9 @@ int az_tower_load_weights(az_engine *h, const float *blob, size_t n_floats);
 /* x int8 (B,17,H,W) host; out_p (B,O), out_v (B) float32 host */
 int az_tower_forward(az_engine *h, const int8_t *planes, int32_t B, float *out_p, float *out_v);
 double az_tower_flops_per_eval(az_engine *h);
+/* on=1: bracket every residual-tower convolution launch of az_selfplay_run with HIP events on the
+ * launch stream and accumulate conv_ms / conv_launches in az_counters (measurement only) */
+int az_tower_profile(az_engine *h, int32_t on);
 
 /* ---- measurement ------------------------------------------------------ */
 int az_counters_get(az_engine *h, az_counters *out);
