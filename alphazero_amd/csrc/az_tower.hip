@@ -174,6 +174,149 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const bf16_t *__restrict__
 }
 
 // ---------------------------------------------------------------------------
+// bf16 implicit-GEMM 3x3 convolution, 256 -> 256 channels: the tower's hot kernel.
+//
+// Workgroup = 512 threads (8 waves) computes a 256-pixel x 256-channel output tile.
+// GEMM orientation: MFMA A operand = weights (rows = output channels), B operand =
+// activations (columns = pixels), so every lane ends up with 4 consecutive channels
+// of one pixel per accumulator.  K step = one tap x 64 input channels (36 steps).
+// Both operand tiles live in LDS as [256 rows][64 bf16] (128 B rows, no padding) in
+// two buffers; they are filled by global_load_lds_dwordx4 (16 B per lane, 8 rows per
+// wave instruction).  The 16-byte slot s of row r holds k-chunk s ^ ((r >> 1) & 7):
+// the XOR is applied to the per-lane GLOBAL address at fill time and to the LDS
+// address at read time, which makes every ds_read_b128 lane group hit 64 distinct
+// banks.  Wave (wr, wc) owns pixels wr*128.. and channels wc*64..: 4 x 8 MFMA
+// 16x16x32 accumulators.
+// Epilogue: + bias -> bf16 -> per-wave LDS transpose ([pixel][channel], 144 B rows)
+// -> 16-byte row reads, + residual, ReLU, 16-byte coalesced NHWC stores.
+// ---------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+#define V2_LDS_BYTES (147456 + 1024)
+
+__device__ __forceinline__ void glds16(const bf16_t *g, unsigned char *l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+template <bool RESID>
+__global__ __launch_bounds__(512) void k_conv3x3_c256_bf16(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
+                                                           const float *__restrict__ bias, const bf16_t *__restrict__ R,
+                                                           bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP)
+{
+    constexpr int C = 256;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[V2_LDS_BYTES];
+    int *rowoff = reinterpret_cast<int *>(smem + 147456);  // padded-pixel index of each tile row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int m0 = blockIdx.x * 256, W2 = Wd + 2;
+    if (tid < 256) {
+        int m = min(m0 + tid, M - 1);
+        int b = m / HW, pix = m - b * HW, y = pix / Wd, x = pix - y * Wd;
+        rowoff[tid] = b * PP + (y + 1) * W2 + (x + 1);
+    }
+    __syncthreads();
+    // fill mapping: wave w fills rows w*32 + q*8 + (lane>>3), slot lane&7, of both tiles
+    const int frow = lane >> 3, fslot = lane & 7;
+    int xoff[4], woff[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int r = wave * 32 + q * 8 + frow;
+        const int kc = fslot ^ ((r >> 1) & 7);
+        xoff[q] = rowoff[r] * C + kc * 8;
+        woff[q] = r * 9 * C + kc * 8;
+    }
+    unsigned char *const fill_base = smem + (wave * 32) * 128;  // + q*1024 (+ buffer, + tile)
+    // read mapping (same for both tiles): row (lane&15) of a 16-row group, k-chunk ks2*4 + (lane>>4)
+    const int rd0 = (lane & 15) * 128 + ((((lane >> 4)) ^ ((lane & 15) >> 1)) << 4);
+    const int rd1 = (lane & 15) * 128 + ((((lane >> 4) + 4) ^ ((lane & 15) >> 1)) << 4);
+    const unsigned char *const wrd = smem + (wc * 64) * 128;
+    const unsigned char *const xrd = smem + 32768 + (wr * 128) * 128;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int step, int buf) {
+        const int tap = step >> 2, c0 = (step & 3) * 64;
+        const int ty = tap / 3, tx = tap - ty * 3;
+        const int toff = ((ty - 1) * W2 + (tx - 1)) * C + c0;
+        const int wofs = tap * C + c0;
+        unsigned char *dst = fill_base + buf * 65536;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            glds16(Wt + woff[q] + wofs, dst + q * 1024);
+            glds16(X + xoff[q] + toff, dst + 32768 + q * 1024);
+        }
+    };
+
+    issue(0, 0);
+    for (int step = 0; step < 36; step++) {
+        const int buf = step & 1;
+        __syncthreads();  // drains this wave's LDS-DMA (vmcnt 0) and fences everybody's reads of the other buffer
+        if (step + 1 < 36) issue(step + 1, buf ^ 1);
+        const unsigned char *wb = wrd + buf * 65536;
+        const unsigned char *xb = xrd + buf * 65536;
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ks2++) {
+            const int rd = ks2 ? rd1 : rd0;
+            bf16x8 wf[4], xf[8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) wf[i] = *reinterpret_cast<const bf16x8 *>(wb + i * 2048 + rd);
+#pragma unroll
+            for (int j = 0; j < 8; j++) xf[j] = *reinterpret_cast<const bf16x8 *>(xb + j * 2048 + rd);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    // ---- epilogue: per-wave transpose through LDS
+    unsigned char *reg = smem + wave * 18432;  // [128 pixels][144 B]
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float4 b4 = *reinterpret_cast<const float4 *>(bias + wc * 64 + i * 16 + (lane >> 4) * 4);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const f32x4 a = acc[i][j];
+            uint2 pk;
+            pk.x = (unsigned)f2bf(a[0] + b4.x) | ((unsigned)f2bf(a[1] + b4.y) << 16);
+            pk.y = (unsigned)f2bf(a[2] + b4.z) | ((unsigned)f2bf(a[3] + b4.w) << 16);
+            *reinterpret_cast<uint2 *>(reg + (j * 16 + (lane & 15)) * 144 + (i * 16 + (lane >> 4) * 4) * 2) = pk;
+        }
+    }
+    __syncthreads();
+    const int erow = lane >> 3, echunk = lane & 7;
+#pragma unroll 4
+    for (int it = 0; it < 16; it++) {
+        const int row = it * 8 + erow;
+        const int trow = wr * 128 + row;
+        if (m0 + trow < M) {
+            uint4 v = *reinterpret_cast<const uint4 *>(reg + row * 144 + echunk * 16);
+            const size_t o = (size_t)rowoff[trow] * C + wc * 64 + echunk * 8;
+            unsigned vv[4] = {v.x, v.y, v.z, v.w};
+            unsigned rr[4] = {0, 0, 0, 0};
+            if (RESID) {
+                uint4 r4 = *reinterpret_cast<const uint4 *>(R + o);
+                rr[0] = r4.x; rr[1] = r4.y; rr[2] = r4.z; rr[3] = r4.w;
+            }
+            unsigned out[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float lo = bf2f((bf16_t)(vv[k] & 0xffff)), hi = bf2f((bf16_t)(vv[k] >> 16));
+                if (RESID) { lo += bf2f((bf16_t)(rr[k] & 0xffff)); hi += bf2f((bf16_t)(rr[k] >> 16)); }
+                out[k] = (unsigned)f2bf(fmaxf(lo, 0.f)) | ((unsigned)f2bf(fmaxf(hi, 0.f)) << 16);
+            }
+            *reinterpret_cast<uint4 *>(Y + o) = make_uint4(out[0], out[1], out[2], out[3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // fp32 implicit-GEMM 3x3 convolution (vector ALU): 64 pixels x 64 channels per
 // workgroup, 4x4 outputs per thread, K step = one tap x 16 channels.
 // ---------------------------------------------------------------------------
@@ -436,6 +579,12 @@ void launch_conv<bf16_t>(const Tower *t, const bf16_t *X, const bf16_t *Wt, cons
 {
     const int M = B * t->HW;
     dim3 grid((M + 127) / 128, t->C / 128), block(256);
+    if (cin == 256 && t->C == 256) {
+        dim3 g2((M + 255) / 256), b2(512);
+        if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16<true>), g2, b2, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP);
+        else hipLaunchKernelGGL((k_conv3x3_c256_bf16<false>), g2, b2, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP);
+        return;
+    }
     if (cin == CIN0)
         hipLaunchKernelGGL((k_conv3x3_bf16<32, false>), grid, block, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C);
     else if (R)
