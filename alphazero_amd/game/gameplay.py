@@ -1,0 +1,121 @@
+"""Drop-in for AlphaZero.game.gameplay (config key gameplay_path): one two-player game.
+
+`Game` keeps the reference's constructor, `start()`, `get_history()`, `.winner`, `.state`
+(game/gameplay.py:17-94).  For thousands of concurrent games use `BatchedSelfplay`, which drives
+the engine's device-side self-play machine and returns the same `get_history()` tuples.
+"""
+import importlib
+
+import numpy as np
+
+from ..engine import Engine, game_config_to_engine_kwargs
+from ..player import mcts_player as player
+
+
+def printlog(*args):
+    pass
+
+
+def history_arrays(eng, moves, visits, winner, slot=0):
+    """(state_np (T,17,H,W) f64, probs_np (T,O) f64, result_np (T,) f64) of game/gameplay.py:73-94,
+    the states re-derived by replaying `moves` through the engine's rule and feature kernels."""
+    T = len(moves)
+    H, W, O = eng.H, eng.W, eng.O
+    state_np = np.zeros((T, 17, H, W))
+    eng.reset([slot])
+    for i in range(T):
+        state_np[i] = eng.features([slot], [0])[0]
+        status, _ = eng.do_move([slot], [int(moves[i])])
+        assert status[0] == 0
+    probs_np = np.asarray(visits, np.float64) / np.asarray(visits, np.float64).sum(axis=1, keepdims=True) if T else np.zeros((0, O))
+    result_np = np.array([1.0 if (i % 2 == (winner != 1)) else -1.0 for i in range(T)])
+    return state_np, probs_np, result_np
+
+
+class Game:
+    def __init__(self, nn_eval_1, nn_eval_2, game_config, ext_config):
+        self.player_1 = player.Player(nn_eval_1, game_config, ext_config['player'])
+        self.player_2 = player.Player(nn_eval_2, game_config, ext_config['player'])
+        self._game_env = importlib.import_module(game_config['env_path'])
+        self.state = self._game_env.GameState()
+        self.winner = None
+        self.state_history = []
+        self.probs_history = []
+        self.acts_history = []
+        self._w = game_config['board_width']
+        self._h = game_config['board_height']
+        self._f = game_config['history_step'] * game_config['planes_per_step'] + game_config['additional_planes']
+        self._o = game_config['flat_move_output']
+        self.dirichlet_before = ext_config['dirichlet_before']
+        self.log_iter = ext_config['log_iter']
+        self.max_turn = ext_config['max_turn']
+
+    def start(self):
+        current_player = self.player_1
+        while not (self.state.is_end_of_game or self.state.turns > self.max_turn):
+            if self.state.turns % self.log_iter == 0:
+                printlog(str(self.state.turns), 'moves')
+            move, probs = current_player.think(self.state, (self.state.turns <= self.dirichlet_before))
+            self.state_history.append(self.state.features(0))  # planes of the pre-move state
+            self.probs_history.append(probs)
+            self.acts_history.append(move)
+            self.state.do_move(move)
+            self.player_1.ack(move)
+            self.player_2.ack(move)
+            current_player = self.player_2 if current_player == self.player_1 else self.player_1
+        self.winner = self.state.get_winner()
+        printlog('end', self.winner)
+        return self.winner
+
+    def get_history(self):
+        n = len(self.probs_history)
+        state_np = np.zeros((len(self.state_history), self._f, self._h, self._w))
+        probs_np = np.zeros((n, self._o))
+        result_np = np.zeros((n))
+        for i in range(n):
+            state_np[i] = self.state_history[i]
+            for action, p in self.probs_history[i]:
+                if action == self._game_env.PASS_MOVE:
+                    probs_np[i, self._w * self._h] = p
+                else:
+                    probs_np[i, action[0] * self._w + action[1]] = p
+            result_np[i] = 1 if (i % 2 == (self.winner != self._game_env.BLACK)) else -1
+        return state_np, probs_np, result_np
+
+
+class BatchedSelfplay:
+    """`n_games` concurrent self-play games on one GPU; the role of Selfplay.run +
+    selfplay_wrapper (train/parallel/selfplay.py:71-108) without a process per game."""
+
+    def __init__(self, nn_eval, game_config, ext_config, n_games, seed=0, device=0):
+        kw = game_config_to_engine_kwargs(game_config)
+        self.eng = Engine(n_slots=n_games, max_playout=ext_config['player']['max_playout'],
+                          dirichlet_before=ext_config['dirichlet_before'], max_turn=ext_config['max_turn'],
+                          record_trajectories=True, seed=seed, num_blocks=nn_eval.num_blocks, channels=nn_eval.channels,
+                          tower_dtype=nn_eval.dtype, device=device, **kw)
+        self._nn_eval = nn_eval
+        self._version = None
+        self._replay = Engine(n_slots=1, **kw)
+        self.n_games = n_games
+        self._started = False
+
+    def _sync_weights(self):
+        if self._version != self._nn_eval.version:
+            self.eng.tower_load(self._nn_eval._tower_blob)
+            self._version = self._nn_eval.version
+
+    def run(self, num_games, rounds_per_poll=64):
+        """Play until `num_games` games have finished; returns their get_history() tuples."""
+        self._sync_weights()
+        if not self._started:
+            self.eng.selfplay_start()
+            self._started = True
+        out = []
+        while len(out) < num_games:
+            self.eng.selfplay_run(rounds_per_poll)
+            _, done = self.eng.selfplay_status()
+            for s in np.flatnonzero(done):
+                tr = self.eng.trajectory_pop(int(s), restart=True)
+                out.append(history_arrays(self._replay, tr["moves"], tr["visits"], tr["winner"]))
+            self._sync_weights()
+        return out[:num_games]

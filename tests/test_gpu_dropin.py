@@ -1,0 +1,221 @@
+"""GPU tests of the drop-in Python modules (env_path / state_converter_path / gameplay_path,
+MCTSearch, Player): written like the reference's own unit tests and compared with fixtures the
+reference produced under the same seeded random draws."""
+import random
+
+import numpy as np
+import pytest
+import yaml
+
+from oracle.fake_eval import fake_eval_planes
+from tests.helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(game, H, W, O, tt, k=None):
+    import os
+    import alphazero_amd
+    with open(os.path.join(os.path.dirname(alphazero_amd.__file__), "config", game + ".yaml")) as f:
+        c = yaml.safe_load(f)
+    c.update(board_height=H, board_width=W, flat_move_output=O, transform_types=tt)
+    if k is not None:
+        c["k"] = k
+    return c
+
+
+class FakeEvaluator:
+    def __init__(self, cfg):
+        import alphazero_amd.processing.state_converter as sc
+        self.cfg = cfg
+        self.conv = sc.StateTensorConverter(cfg)
+        self.t2a = sc.TensorActionConverter(cfg)
+        self.calls = 0
+
+    def eval(self, state):
+        self.calls += 1
+        planes = self.conv.state_to_tensor(state)[0]
+        pri, v = fake_eval_planes(planes, self.cfg["flat_move_output"])
+        return self.t2a.tensor_to_action(pri), v
+
+    def load(self, p): pass
+    def save(self, p): pass
+
+
+def _install_seeded_draws(seed):
+    """Same generators the fixture generator fed the reference with."""
+    import alphazero_amd.search.mcts as mcts
+    nprng = np.random.RandomState(seed)
+    pyrng = random.Random(seed)
+    saved = (mcts.randint, mcts.random_variate_dirichlet, mcts.weighted_random_choice)
+    mcts.randint = lambda n: int(nprng.randint(n))
+    mcts.random_variate_dirichlet = lambda alpha, n: [pyrng.gammavariate(alpha, 1) for _ in range(n)]
+
+    def wrc(li):
+        p, w = zip(*li)
+        return pyrng.choices(p, weights=w)[0]
+    mcts.weighted_random_choice = wrc
+    return saved
+
+
+def _restore(saved):
+    import alphazero_amd.search.mcts as mcts
+    mcts.randint, mcts.random_variate_dirichlet, mcts.weighted_random_choice = saved
+
+
+@pytest.mark.parametrize("name,seed", [("search_ttt_game", 21), ("search_reversi_game", 24)])
+def test_game_class_reproduces_reference_game(name, seed):
+    g = load_golden(name)
+    game, H, W, k, O = str(g["game"]), int(g["H"]), int(g["W"]), int(g["k"]), int(g["O"])
+    cfg = _cfg(game, H, W, O, int(g["transform_types"]), k or None)
+    if game == "mnk":
+        import alphazero_amd.env.mnk as mnk
+        mnk.game_config.update(board_height=H, board_width=W, k=k)
+    import alphazero_amd.game.gameplay as gameplay
+    ext = {"player": {"max_playout": int(g["max_playout"])}, "dirichlet_before": int(g["dirichlet_before"]),
+           "log_iter": 10 ** 9, "max_turn": int(g["max_turn"])}
+    saved = _install_seeded_draws(seed)
+    try:
+        ev = FakeEvaluator(cfg)
+        gm = gameplay.Game(ev, ev, cfg, ext)
+        winner = gm.start()
+        s, p, r = gm.get_history()
+    finally:
+        _restore(saved)
+    assert winner == g["winner"]
+    assert [gm.state._a2i(m) for m in gm.acts_history] == list(g["moves"])
+    assert ev.calls == g["total_evals"]
+    assert np.array_equal(s, g["hist_state"].astype(np.float64))
+    assert np.array_equal(p, g["hist_probs"])
+    assert np.array_equal(r, g["hist_result"])
+    assert np.array_equal(gm.state.board, g["final_board"])
+
+
+def test_mcts_known_answers_of_reference_unit_tests():
+    """tests/test_mcts.py of the reference: playout/expansion counts, re-root, next selection."""
+    import alphazero_amd.env.go as go
+    from alphazero_amd.search.mcts import MCTSearch
+    cfg = _cfg("go", 19, 19, 362, 0)
+    d = np.arange(361, dtype=np.float64)
+    d = d / d.sum()
+
+    def policy_value(state):
+        moves = [(x, y) for x in range(19) for y in range(19)]
+        pol = list(zip(moves, d.astype(np.float32)))
+        pol.append((None, np.float32(0)))
+        return pol, np.float32(0.0)
+
+    gs = go.GameState()
+    m = MCTSearch(policy_value, cfg, max_playout=1)
+    move = m.calc_move(gs, prop_exp=False)
+    assert move == (18, 18)
+    gs.do_move(move)
+    m.update_with_move(move)
+    root = m._root
+    assert len(root._children) > 0 and root._parent is None
+    # after one more playout the visited child is the next best prior: (18, 17)
+    m.calc_move(gs, prop_exp=False)
+    ch = m._root._children
+    assert max(ch.items(), key=lambda kv: kv[1].visit_count)[0] == (18, 17)
+    # 8 playouts from a fresh tree: 362 children, 8 expansions below the root
+    m2 = MCTSearch(policy_value, cfg, max_playout=8)
+    m2._calc_move(go.GameState())
+    ch = m2._root._children
+    assert len(ch) == 362 and ch[(18, 18)].visit_count == 1
+    edges, blocks = m2._eng.tree_size(0, 0)
+    assert blocks - 1 == 8
+
+
+def test_env_go_known_answers():
+    """simple_board() of tests/test_go_state_converter.py / test_transformer.py on the env shim."""
+    import alphazero_amd.env.go as go
+    import alphazero_amd.processing.state_converter as sc
+    gs = go.GameState(size=7)
+    for mv in [(0, 0), (1, 0), (0, 1), (1, 1), (0, 2), (3, 4), (3, 3), (4, 5), (4, 2), (5, 4), (5, 3), (4, 3), (4, 4)]:
+        gs.do_move(mv)
+    target = np.asarray([
+        [1, 1, 1, 0, 0, 0, 0], [-1, -1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0, 0], [0, 0, 0, 1, -1, 0, 0],
+        [0, 0, 1, 0, 1, -1, 0], [0, 0, 0, 1, -1, 0, 0], [0, 0, 0, 0, 0, 0, 0]])
+    assert np.array_equal(gs.board, target)
+    assert gs.ko == (4, 3) and not gs.is_legal((4, 3)) and gs.is_legal(None)
+    assert gs.current_player == go.WHITE and gs.num_white_prisoners == 1
+    with pytest.raises(go.IllegalMove):
+        gs.do_move((0, 0))
+    c = gs.copy()
+    c.transform(1)
+    assert np.array_equal(c.board, np.rot90(target, 1))
+    assert np.array_equal(gs.board, target)  # the copy is independent
+    cfg = _cfg("go", 7, 7, 50, 8)
+    pp = sc.StateTensorConverter(cfg, ["board_history"])
+    pc = sc.StateTensorConverter(cfg, ["color"])
+    pall = sc.StateTensorConverter(cfg)
+    t = pall.state_to_tensor(gs)
+    assert t.shape == (1, 17, 7, 7) and t.dtype == np.int8
+    assert np.array_equal(t[0][:-1], pp.state_to_tensor(gs)[0]) and np.array_equal(t[0][-1:], pc.state_to_tensor(gs)[0])
+    assert np.all(pc.state_to_tensor(gs) == 0)
+    assert np.array_equal(t[0][14], (target == -1)) and np.array_equal(t[0][15], (target == 1))
+    # forward o reverse transform == identity for all ids (tests/test_transformer.py:90-101)
+    rt = sc.ReverseTransformer(cfg).reverse_transform
+    for tid in range(8):
+        g2 = gs.copy()
+        g2.transform(tid)
+        b = g2.board
+        ap = [((i, j), b[i][j]) for i in range(7) for j in range(7)] + [(None, 0)]
+        rt(ap, tid)
+        for (x, y), p in ap[:49]:
+            assert p == target[x][y]
+    with pytest.raises(ValueError):
+        sc.StateTensorConverter(cfg, ["nope"])
+
+
+def test_env_reversi_and_mnk_basics():
+    import alphazero_amd.env.mnk as mnk
+    import alphazero_amd.env.reversi as rv
+    r = rv.GameState()
+    assert sorted(r.get_legal_moves()) == [(2, 3), (3, 2), (4, 5), (5, 4)]
+    assert not r.is_legal(None)
+    assert r.do_move((2, 3)) is False
+    assert r.board[3][3] == rv.BLACK and r.stones_played == 5 and r.current_player == rv.WHITE
+    mnk.game_config.update(board_height=3, board_width=3, k=3)
+    m = mnk.GameState()
+    for mv in [(0, 0), (1, 0), (0, 1), (1, 1)]:
+        assert m.do_move(mv) is False
+    assert m.get_winner() is None
+    assert m.do_move((0, 2)) is True
+    assert m.get_winner() == mnk.BLACK and m.is_end_of_game and m.copy().winner == mnk.BLACK
+    with pytest.raises(mnk.IllegalMove):
+        m.do_move((0, 0))
+    mnk.game_config.update(board_height=6, board_width=5, k=4)
+
+
+def test_nn_evaluator_player_and_batched_selfplay():
+    """NNEvaluator contract + device-resident search through Player, and BatchedSelfplay histories."""
+    import alphazero_amd.env.mnk as mnk
+    from alphazero_amd.evaluator.nn_eval import NNEvaluator
+    from alphazero_amd.game.gameplay import BatchedSelfplay
+    from alphazero_amd.player.mcts_player import Player
+    from oracle import tower_ref
+    import torch
+    cfg = _cfg("mnk", 3, 3, 9, 0, 3)
+    mnk.game_config.update(board_height=3, board_width=3, k=3)
+    ev = NNEvaluator(cfg, num_blocks=1, channels=128, dtype="fp32", max_batch_size=4, seed=5)
+    st = mnk.GameState()
+    st.do_move((1, 1))
+    pol, v = ev.eval(st)
+    assert len(pol) == 9 and pol[0][0] == (0, 0)
+    rp, rv = tower_ref.forward(ev.net.state_dict(), torch.from_numpy(st.features(0)).float()[None], 1)
+    assert np.abs(np.array([p for _, p in pol]) - rp[0].numpy()).max() < 1e-5 and abs(v - float(rv[0])) < 1e-5
+    ev.rwlock.r_acquire(); ev.rwlock.r_release()
+    pl = Player(ev, cfg, {"max_playout": 30})
+    move, probs = pl.think(st, True)
+    assert st.is_legal(move) and abs(sum(p for _, p in probs) - 1.0) < 1e-9 and len(probs) == 8
+    pl.ack(move)
+    bs = BatchedSelfplay(ev, cfg, {"player": {"max_playout": 20}, "dirichlet_before": 30, "max_turn": 400}, n_games=8, seed=3)
+    hist = bs.run(10)
+    assert len(hist) == 10
+    for s, p, r in hist:
+        T = s.shape[0]
+        assert 5 <= T <= 9 and s.shape == (T, 17, 3, 3) and p.shape == (T, 9) and r.shape == (T,)
+        assert np.allclose(p.sum(axis=1), 1.0) and set(np.unique(r)) <= {-1.0, 1.0}
+        assert np.all(s[0][:16] == 0) and np.all(s[0][16] == 1)
+    mnk.game_config.update(board_height=6, board_width=5, k=4)
