@@ -14,11 +14,7 @@
 #include <cstring>
 #include <vector>
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef unsigned short bf16_t;
-
-#define CIN0 32  // input planes (17) padded to one K chunk
+#include "az_conv_kernels.h"
 
 struct Tower {
     int H, W, HW, PP, O, NB, C, dtype, maxB;
@@ -40,15 +36,6 @@ struct Tower {
     unsigned long long conv_launches;
 };
 
-__device__ __forceinline__ bf16_t f2bf(float f)
-{
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
-    return (bf16_t)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((unsigned int)b) << 16); }
-
 static inline bf16_t h_f2bf(float f)
 {
     unsigned int u;
@@ -56,325 +43,6 @@ static inline bf16_t h_f2bf(float f)
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
-}
-
-// ---------------------------------------------------------------------------
-// int8 planes (B,17,H,W) -> NHWC with halo, CIN0 channels (17 real + zeros)
-// ---------------------------------------------------------------------------
-template <typename T>
-__global__ void k_planes_to_nhwc(const int8_t *planes, T *X0, int H, int W)
-{
-    const int b = blockIdx.x, HW = H * W, PP = (H + 2) * (W + 2);
-    const int8_t *src = planes + (size_t)b * 17 * HW;
-    for (int idx = threadIdx.x; idx < HW * CIN0; idx += blockDim.x) {
-        int pix = idx / CIN0, c = idx - pix * CIN0;
-        int y = pix / W, x = pix - y * W;
-        float v = c < 17 ? (float)src[c * HW + pix] : 0.0f;
-        size_t o = ((size_t)b * PP + (y + 1) * (W + 2) + (x + 1)) * CIN0 + c;
-        if constexpr (sizeof(T) == 2) X0[o] = f2bf(v); else X0[o] = v;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// bf16 implicit-GEMM 3x3 convolution on MFMA.
-// Workgroup tile 128 pixels x 128 output channels, 4 waves as 2x2, each wave a
-// 64x64 tile = 2x2 MFMA 32x32 accumulators; K step = one tap x KC channels.
-// ---------------------------------------------------------------------------
-template <int KC, bool RESID>
-__global__ __launch_bounds__(256) void k_conv3x3_bf16(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
-                                                      const float *__restrict__ bias, const bf16_t *__restrict__ R,
-                                                      bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP, int CIN, int COUT)
-{
-    constexpr int LDK = KC + 8;          // +16 B per row: conflict-free 16-byte fragment reads
-    constexpr int CPR = KC / 8;          // 16-byte chunks per row
-    constexpr int RPP = 256 / CPR;       // rows loaded per pass
-    constexpr int NP = 128 / RPP;        // passes
-    __shared__ __attribute__((aligned(16))) bf16_t As[128 * LDK];
-    __shared__ __attribute__((aligned(16))) bf16_t Bs[128 * LDK];
-    __shared__ int rowoff[128];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
-    const int W2 = Wd + 2;
-
-    if (tid < 128) {
-        int m = min(m0 + tid, M - 1);
-        int b = m / HW, pix = m - b * HW, y = pix / Wd, x = pix - y * Wd;
-        rowoff[tid] = b * PP + (y + 1) * W2 + (x + 1);
-    }
-    __syncthreads();
-    const int lrow = tid / CPR, lch = tid - lrow * CPR;
-    size_t abase[NP], wbase[NP];
-#pragma unroll
-    for (int p = 0; p < NP; p++) {
-        abase[p] = (size_t)rowoff[lrow + p * RPP] * CIN + lch * 8;
-        wbase[p] = (size_t)(n0 + lrow + p * RPP) * 9 * CIN + lch * 8;
-    }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-
-    for (int tap = 0; tap < 9; tap++) {
-        const long toff = (long)((tap / 3 - 1) * W2 + (tap % 3 - 1)) * CIN;
-        for (int c0 = 0; c0 < CIN; c0 += KC) {
-            uint4 ra[NP], rb[NP];
-#pragma unroll
-            for (int p = 0; p < NP; p++) {
-                ra[p] = *reinterpret_cast<const uint4 *>(X + (long)abase[p] + toff + c0);
-                rb[p] = *reinterpret_cast<const uint4 *>(Wt + wbase[p] + (size_t)tap * CIN + c0);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int p = 0; p < NP; p++) {
-                *reinterpret_cast<uint4 *>(&As[(lrow + p * RPP) * LDK + lch * 8]) = ra[p];
-                *reinterpret_cast<uint4 *>(&Bs[(lrow + p * RPP) * LDK + lch * 8]) = rb[p];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int ks = 0; ks < KC / 16; ks++) {
-                bf16x8 af[2], bf[2];
-                const int kk = ks * 16 + 8 * (lane >> 5);
-#pragma unroll
-                for (int i = 0; i < 2; i++) {
-                    af[i] = *reinterpret_cast<const bf16x8 *>(&As[(wr * 64 + i * 32 + (lane & 31)) * LDK + kk]);
-                    bf[i] = *reinterpret_cast<const bf16x8 *>(&Bs[(wc * 64 + i * 32 + (lane & 31)) * LDK + kk]);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int j = 0; j < 2; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-            }
-        }
-    }
-    // epilogue: + bias (+ residual), ReLU, bf16, NHWC store
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int n = n0 + wc * 64 + j * 32 + (lane & 31);
-        const float bn = bias[n];
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m0 + row < M) {
-                    size_t o = (size_t)rowoff[row] * COUT + n;
-                    float v = acc[i][j][r] + bn;
-                    if (RESID) v += bf2f(R[o]);
-                    Y[o] = f2bf(fmaxf(v, 0.0f));
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// bf16 implicit-GEMM 3x3 convolution, 256 -> 256 channels: the tower's hot kernel.
-//
-// Workgroup = 512 threads (8 waves) computes a 256-pixel x 256-channel output tile.
-// GEMM orientation: MFMA A operand = weights (rows = output channels), B operand =
-// activations (columns = pixels), so every lane ends up with 4 consecutive channels
-// of one pixel per accumulator.  K step = one tap x 64 input channels (36 steps).
-// Both operand tiles live in LDS as [256 rows][64 bf16] (128 B rows, no padding) in
-// two buffers; they are filled by global_load_lds_dwordx4 (16 B per lane, 8 rows per
-// wave instruction).  The 16-byte slot s of row r holds k-chunk s ^ ((r >> 1) & 7):
-// the XOR is applied to the per-lane GLOBAL address at fill time and to the LDS
-// address at read time, which makes every ds_read_b128 lane group hit 64 distinct
-// banks.  Wave (wr, wc) owns pixels wr*128.. and channels wc*64..: 4 x 8 MFMA
-// 16x16x32 accumulators.
-// Epilogue: + bias -> bf16 -> per-wave LDS transpose ([pixel][channel], 144 B rows)
-// -> 16-byte row reads, + residual, ReLU, 16-byte coalesced NHWC stores.
-// ---------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-#define V2_LDS_BYTES (147456 + 1024)
-
-__device__ __forceinline__ void glds16(const bf16_t *g, unsigned char *l)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
-}
-
-template <bool RESID>
-__global__ __launch_bounds__(512) void k_conv3x3_c256_bf16(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
-                                                           const float *__restrict__ bias, const bf16_t *__restrict__ R,
-                                                           bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP)
-{
-    constexpr int C = 256;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[V2_LDS_BYTES];
-    int *rowoff = reinterpret_cast<int *>(smem + 147456);  // padded-pixel index of each tile row
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
-    const int m0 = blockIdx.x * 256, W2 = Wd + 2;
-    if (tid < 256) {
-        int m = min(m0 + tid, M - 1);
-        int b = m / HW, pix = m - b * HW, y = pix / Wd, x = pix - y * Wd;
-        rowoff[tid] = b * PP + (y + 1) * W2 + (x + 1);
-    }
-    __syncthreads();
-    // fill mapping: wave w fills rows w*32 + q*8 + (lane>>3), slot lane&7, of both tiles
-    const int frow = lane >> 3, fslot = lane & 7;
-    int xoff[4], woff[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int r = wave * 32 + q * 8 + frow;
-        const int kc = fslot ^ ((r >> 1) & 7);
-        xoff[q] = rowoff[r] * C + kc * 8;
-        woff[q] = r * 9 * C + kc * 8;
-    }
-    unsigned char *const fill_base = smem + (wave * 32) * 128;  // + q*1024 (+ buffer, + tile)
-    // read mapping (same for both tiles): row (lane&15) of a 16-row group, k-chunk ks2*4 + (lane>>4)
-    const int rd0 = (lane & 15) * 128 + ((((lane >> 4)) ^ ((lane & 15) >> 1)) << 4);
-    const int rd1 = (lane & 15) * 128 + ((((lane >> 4) + 4) ^ ((lane & 15) >> 1)) << 4);
-    const unsigned char *const wrd = smem + (wc * 64) * 128;
-    const unsigned char *const xrd = smem + 32768 + (wr * 128) * 128;
-
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    auto issue = [&](int step, int buf) {
-        const int tap = step >> 2, c0 = (step & 3) * 64;
-        const int ty = tap / 3, tx = tap - ty * 3;
-        const int toff = ((ty - 1) * W2 + (tx - 1)) * C + c0;
-        const int wofs = tap * C + c0;
-        unsigned char *dst = fill_base + buf * 65536;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            glds16(Wt + woff[q] + wofs, dst + q * 1024);
-            glds16(X + xoff[q] + toff, dst + 32768 + q * 1024);
-        }
-    };
-
-    issue(0, 0);
-    for (int step = 0; step < 36; step++) {
-        const int buf = step & 1;
-        __syncthreads();  // drains this wave's LDS-DMA (vmcnt 0) and fences everybody's reads of the other buffer
-        if (step + 1 < 36) issue(step + 1, buf ^ 1);
-        const unsigned char *wb = wrd + buf * 65536;
-        const unsigned char *xb = xrd + buf * 65536;
-#pragma unroll
-        for (int ks2 = 0; ks2 < 2; ks2++) {
-            const int rd = ks2 ? rd1 : rd0;
-            bf16x8 wf[4], xf[8];
-#pragma unroll
-            for (int i = 0; i < 4; i++) wf[i] = *reinterpret_cast<const bf16x8 *>(wb + i * 2048 + rd);
-#pragma unroll
-            for (int j = 0; j < 8; j++) xf[j] = *reinterpret_cast<const bf16x8 *>(xb + j * 2048 + rd);
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    // ---- epilogue: per-wave transpose through LDS
-    unsigned char *reg = smem + wave * 18432;  // [128 pixels][144 B]
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const float4 b4 = *reinterpret_cast<const float4 *>(bias + wc * 64 + i * 16 + (lane >> 4) * 4);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const f32x4 a = acc[i][j];
-            uint2 pk;
-            pk.x = (unsigned)f2bf(a[0] + b4.x) | ((unsigned)f2bf(a[1] + b4.y) << 16);
-            pk.y = (unsigned)f2bf(a[2] + b4.z) | ((unsigned)f2bf(a[3] + b4.w) << 16);
-            *reinterpret_cast<uint2 *>(reg + (j * 16 + (lane & 15)) * 144 + (i * 16 + (lane >> 4) * 4) * 2) = pk;
-        }
-    }
-    __syncthreads();
-    const int erow = lane >> 3, echunk = lane & 7;
-#pragma unroll 4
-    for (int it = 0; it < 16; it++) {
-        const int row = it * 8 + erow;
-        const int trow = wr * 128 + row;
-        if (m0 + trow < M) {
-            uint4 v = *reinterpret_cast<const uint4 *>(reg + row * 144 + echunk * 16);
-            const size_t o = (size_t)rowoff[trow] * C + wc * 64 + echunk * 8;
-            unsigned vv[4] = {v.x, v.y, v.z, v.w};
-            unsigned rr[4] = {0, 0, 0, 0};
-            if (RESID) {
-                uint4 r4 = *reinterpret_cast<const uint4 *>(R + o);
-                rr[0] = r4.x; rr[1] = r4.y; rr[2] = r4.z; rr[3] = r4.w;
-            }
-            unsigned out[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                float lo = bf2f((bf16_t)(vv[k] & 0xffff)), hi = bf2f((bf16_t)(vv[k] >> 16));
-                if (RESID) { lo += bf2f((bf16_t)(rr[k] & 0xffff)); hi += bf2f((bf16_t)(rr[k] >> 16)); }
-                out[k] = (unsigned)f2bf(fmaxf(lo, 0.f)) | ((unsigned)f2bf(fmaxf(hi, 0.f)) << 16);
-            }
-            *reinterpret_cast<uint4 *>(Y + o) = make_uint4(out[0], out[1], out[2], out[3]);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// fp32 implicit-GEMM 3x3 convolution (vector ALU): 64 pixels x 64 channels per
-// workgroup, 4x4 outputs per thread, K step = one tap x 16 channels.
-// ---------------------------------------------------------------------------
-template <bool RESID>
-__global__ __launch_bounds__(256) void k_conv3x3_f32(const float *__restrict__ X, const float *__restrict__ Wt,
-                                                     const float *__restrict__ bias, const float *__restrict__ R,
-                                                     float *__restrict__ Y, int M, int HW, int Wd, int PP, int CIN, int COUT)
-{
-    __shared__ float As[16][64 + 4];
-    __shared__ float Bs[16][64 + 4];
-    __shared__ int rowoff[64];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64, W2 = Wd + 2;
-    if (tid < 64) {
-        int m = min(m0 + tid, M - 1);
-        int b = m / HW, pix = m - b * HW, y = pix / Wd, x = pix - y * Wd;
-        rowoff[tid] = b * PP + (y + 1) * W2 + (x + 1);
-    }
-    __syncthreads();
-    // loader: 64 rows x 16 k = 1024 floats, 4 per thread (one float4 along k)
-    const int lrow = tid >> 2, lk = (tid & 3) * 4;
-    const size_t abase = (size_t)rowoff[lrow] * CIN + lk;
-    const size_t wbase = (size_t)(n0 + lrow) * 9 * CIN + lk;
-    float acc[4][4] = {};
-    for (int tap = 0; tap < 9; tap++) {
-        const long toff = (long)((tap / 3 - 1) * W2 + (tap % 3 - 1)) * CIN;
-        for (int c0 = 0; c0 < CIN; c0 += 16) {
-            float4 a = *reinterpret_cast<const float4 *>(X + (long)abase + toff + c0);
-            float4 w = *reinterpret_cast<const float4 *>(Wt + wbase + (size_t)tap * CIN + c0);
-            __syncthreads();
-            As[lk + 0][lrow] = a.x; As[lk + 1][lrow] = a.y; As[lk + 2][lrow] = a.z; As[lk + 3][lrow] = a.w;
-            Bs[lk + 0][lrow] = w.x; Bs[lk + 1][lrow] = w.y; Bs[lk + 2][lrow] = w.z; Bs[lk + 3][lrow] = w.w;
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                float av[4], bv[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) { av[i] = As[k][ty * 4 + i]; bv[i] = Bs[k][tx * 4 + i]; }
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int row = ty * 4 + i;
-        if (m0 + row >= M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int n = n0 + tx * 4 + j;
-            size_t o = (size_t)rowoff[row] * COUT + n;
-            float v = acc[i][j] + bias[n];
-            if (RESID) v += R[o];
-            Y[o] = fmaxf(v, 0.0f);
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------
