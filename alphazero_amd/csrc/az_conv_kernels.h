@@ -699,13 +699,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
         for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 wf[4], xf[8];
 
-    auto issue_w = [&](int h) {
+    int opaque0 = 0;  // re-defined by an empty asm every chunk so that per-tap addresses are not hoisted into VGPRs
+    // (cc, tap) = 32-channel chunk and filter tap of half-step h = 9*cc + tap; ring slot of its weights = h & 3
+    auto issue_w = [&](int cc, int tap) {
 #ifdef ABL_NODMA
-        if (h > 3) return;
+        if (cc > 0) return;
 #endif
-        const int cc = h / 9, tap = h - cc * 9;
-        const int wofs = tap * C + cc * 32;
-        unsigned char *dst = wfill + (h & 3) * 16384;
+        const int wofs = tap * C + cc * 32 + opaque0;
+        unsigned char *dst = wfill + ((cc + tap) & 3) * 16384;
 #pragma unroll
         for (int q = 0; q < 2; q++) glds16(Wt + woff[q] + wofs, dst + q * 1024);
     };
@@ -717,11 +718,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
 #pragma unroll
         for (int i = 0; i < NSP; i++) glds16(X + soff[i] + cc * 32, dst + i * 8192);
     };
-    auto rd_frags = [&](int h) {
-        const int cc = h / 9, tap = h - cc * 9;
+    auto rd_frags = [&](int cc, int tap) {
+#ifdef ABL_NOREAD
+        if (cc > 0) return;
+#endif
         const int ty = tap / 3, tx = tap - ty * 3;
-        const int tshift = ((ty - 1) * W2 + (tx - 1)) * 64;  // relative to the pixel's own row
-        const unsigned char *wb = smem + (h & 3) * 16384 + wrdo;
+        const int tshift = ((ty - 1) * W2 + (tx - 1)) * 64 + opaque0;  // relative to the pixel's own row
+        const unsigned char *wb = smem + ((cc + tap) & 3) * 16384 + wrdo;
         const unsigned char *sb = smem + V5_SLAB0 + (cc & 1) * SLAB_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; i++) wf[i] = *reinterpret_cast<const bf16x8 *>(wb + i * 1024);
@@ -731,69 +734,85 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
             xf[j] = *reinterpret_cast<const bf16x8 *>(sb + (a ^ ((a & 256) >> 3)));  // slot ^= 2 when row bit 2 is set
         }
     };
-    auto mfmas = [&]() {
+    auto mfma_rows = [&](int i0, int i1) {
 #ifdef ABL_NOMFMA
         asm volatile("" :: "v"(wf[0]), "v"(xf[0]), "v"(wf[3]), "v"(xf[7]));
         return;
 #endif
-#ifndef NO_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = i0; i < i1; i++)
 #pragma unroll
             for (int j = 0; j < 8; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-#ifndef NO_SETPRIO
+    };
+    // One MFMA interval: 32 MFMAs with this wave's share of the LDS-DMA slipped in after the first rows.
+    // dw = how many half-steps ahead the weights are fetched (3 for group 0, 2 for group 1, which issues
+    // one interval later); slab_tap = the tap at which the next chunk's slab is issued.
+    auto mfma_interval = [&](int cc, int tap, int dw, int slab_tap) {
+        __builtin_amdgcn_s_setprio(1);
+        mfma_rows(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int tn = tap + dw;
+        if (tn < 9) issue_w(cc, tn);
+        else if (cc < 7) issue_w(cc + 1, tn - 9);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_rows(1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap == slab_tap && cc < 7) issue_slab(cc + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_rows(2, 4);
         __builtin_amdgcn_s_setprio(0);
-#endif
     };
-    // Every wave issues its share of the LDS-DMA at the head of its own MFMA interval for half-step h:
-    // the weights of half-step h+3 and, in the first half-step of a chunk, the slab of the next chunk.
-    // The target ring buffer was last read two intervals earlier (half-step h-1).
-    auto issue_for = [&](int h) {
-        if (h + 3 < NH) issue_w(h + 3);
-        const int cc = h / 9;
-        if (h - cc * 9 == 0 && cc + 1 < 8) issue_slab(cc + 1);
-    };
-    // Group 0 retires at the end of its MFMA interval of half-step h (it has issued up to W(h+3));
-    // group 1 at the end of its read interval of half-step h (it has issued up to W(h+2)).
-    // Either way W(h+1) - and from the 4th half-step of a chunk on the next slab - must have landed.
-    auto retire = [&](int h, int ahead /* weight batches allowed in flight */) {
-        const int cc = h / 9, ph = h - cc * 9;
-        const int left = NH - 2 - h;  // batches younger than W(h+1) that exist at all
-        const int fly = left < ahead ? (left < 0 ? 0 : left) : ahead;
-        const bool slab_young = (cc + 1 < 8) && (ahead == 2 ? ph < 3 : (ph >= 1 && ph < 3));
-        if (fly == 2) { if (slab_young) wait_vmcnt<4 + NSP>(); else wait_vmcnt<4>(); }
-        else if (fly == 1) { if (slab_young) wait_vmcnt<2 + NSP>(); else wait_vmcnt<2>(); }
+    // vmcnt bookkeeping (per wave, in issue order): before half-step h+1 is read its weights must have
+    // landed; `ahead` younger weight batches (2 glds each) may stay in flight, plus the NSP slab pieces
+    // while they are younger than W(h+1).
+    auto retire_g0 = [&](int cc, int tap) {  // end of group 0's MFMA interval of (cc, tap); issued up to W(h+3)
+        if (cc < 7) { if (tap < 3) wait_vmcnt<4 + NSP>(); else wait_vmcnt<4>(); }
+        else if (tap <= 5) wait_vmcnt<4>();
+        else if (tap == 6) wait_vmcnt<2>();
         else wait_vmcnt<0>();
     };
+    auto retire_g1 = [&](int cc, int tap) {  // end of group 1's read interval of (cc, tap); issued up to W(h+2)
+        if (cc < 7) { if (tap == 1 || tap == 2) wait_vmcnt<2 + NSP>(); else wait_vmcnt<2>(); }
+        else if (tap <= 6) wait_vmcnt<2>();
+        else wait_vmcnt<0>();
+    };
+#define SB() __builtin_amdgcn_sched_barrier(0)
 
-    issue_slab(0); issue_w(0); issue_w(1); issue_w(2);
+    issue_slab(0); issue_w(0, 0); issue_w(0, 1); issue_w(0, 2);
     wait_vmcnt<4>();
     PP_BAR();
     if (wr == 0) {
-        for (int h = 0; h < NH; h++) {
-            rd_frags(h);
-            PP_BAR();
-            issue_for(h);
-            mfmas();
-            retire(h, 2);
-            PP_BAR();
+        for (int cc = 0; cc < 8; cc++) {
+            asm volatile("" : "+s"(opaque0));
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                rd_frags(cc, tap);
+                SB(); PP_BAR(); SB();
+                mfma_interval(cc, tap, 3, 0);
+                retire_g0(cc, tap);
+                SB(); PP_BAR(); SB();
+            }
         }
         PP_BAR();
     } else {
-        for (int h = 0; h < NH; h++) {
-            if (h > 0) { issue_for(h - 1); mfmas(); }
-            PP_BAR();
-            rd_frags(h);
-            retire(h, 1);
-            PP_BAR();
+        for (int cc = 0; cc < 8; cc++) {
+            asm volatile("" : "+s"(opaque0));
+#pragma unroll
+            for (int tap = 0; tap < 9; tap++) {
+                // MFMAs of the previous half-step (its fragments were read one interval ago)
+                if (tap > 0) mfma_interval(cc, tap - 1, 3, 0);
+                else if (cc > 0) mfma_interval(cc - 1, 8, 3, 0);
+                SB(); PP_BAR(); SB();
+                rd_frags(cc, tap);
+                retire_g1(cc, tap);
+                SB(); PP_BAR(); SB();
+            }
         }
-        issue_for(NH - 1);
-        mfmas();
+        mfma_interval(7, 8, 3, 0);
         PP_BAR();
     }
+#undef SB
     __syncthreads();
     conv_epilogue<RESID>(smem, rowoff, acc, bias, R, Y, M, m0, wave, lane, wr, wc);
 }

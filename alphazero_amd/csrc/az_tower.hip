@@ -248,6 +248,8 @@ void launch_conv<bf16_t>(const Tower *t, const bf16_t *X, const bf16_t *Wt, cons
     const int M = B * t->HW;
     dim3 grid((M + 127) / 128, t->C / 128), block(256);
     if (cin == 256 && t->C == 256) {
+        // slab kernel when a 256-pixel tile spans at most 512 padded positions (boards of 8x8 and larger)
+        if (launch_v5(X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, st)) return;
         dim3 g2((M + 255) / 256), b2(512);
         if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16<true>), g2, b2, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP);
         else hipLaunchKernelGGL((k_conv3x3_c256_bf16<false>), g2, b2, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP);

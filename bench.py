@@ -161,7 +161,7 @@ def main():
                                   "finish_move_reroot": c["finish_ms"] / args.steps},
             "tree_stats_per_sim": {"levels": c["levels"] / max(c["evals"], 1), "children_scanned": c["children_scanned"] / max(c["evals"], 1)},
             "roofline": {
-                "bound": "mfma", "kernel": "k_conv3x3_bf16<64> (3x3 256->256 implicit GEMM)",
+                "bound": "mfma", "kernel": "k_conv3x3_c256_bf16_slab (3x3 256->256 implicit GEMM, bf16 MFMA 16x16x32)",
                 "achieved": achieved, "peak": HBM_PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
                 "frac": achieved / HBM_PEAK_TFLOPS_BF16, "traffic": None,
                 "avg_launch_ms": conv_ms, "launches": c["conv_launches"], "flops_per_launch": c["conv_flops_per_launch"],
