@@ -21,7 +21,21 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_TFLOPS_BF16 = 2500.0  # dense bf16 MFMA peak of one MI355X, TFLOP/s
+MFMA_PEAK_TFLOPS_BF16 = 2500.0  # dense bf16 MFMA peak of one MI355X, TFLOP/s
+
+
+def measured_traffic(games, board, channels):
+    """HBM bytes per launch of the dominant conv kernel from the committed PMC passes (they cannot be
+    collected inside a timed run); None when the workload is not the one the counters were taken on."""
+    path = os.path.join(ROOT, "profiles", "round1_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except OSError:
+        return None, None
+    if (d.get("boards"), d.get("board"), d.get("channels")) != (games, board, channels):
+        return None, None
+    return d["traffic_bytes_per_launch"], d["source"]
 
 
 def cpu_baseline(H, num_blocks, channels, sims, budget_s=20.0):
@@ -143,6 +157,7 @@ def main():
     if rank == 0:
         conv_ms = c["conv_ms"] / max(c["conv_launches"], 1)
         achieved = c["conv_flops_per_launch"] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic(args.games, H, args.channels) if args.dtype == "bf16" else (None, None)
         out = {
             "metric": "self-play moves/sec + MCTS sims/sec (node), Go 19x19 800 sims, 1/2/4/8 GPUs",
             "value": moves_per_s, "unit": "moves/s", "sims_per_sec": sims_per_s,
@@ -162,8 +177,8 @@ def main():
             "tree_stats_per_sim": {"levels": c["levels"] / max(c["evals"], 1), "children_scanned": c["children_scanned"] / max(c["evals"], 1)},
             "roofline": {
                 "bound": "mfma", "kernel": "k_conv3x3_c256_bf16_slab (3x3 256->256 implicit GEMM, bf16 MFMA 16x16x32)",
-                "achieved": achieved, "peak": HBM_PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
-                "frac": achieved / HBM_PEAK_TFLOPS_BF16, "traffic": None,
+                "achieved": achieved, "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_PEAK_TFLOPS_BF16, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": conv_ms, "launches": c["conv_launches"], "flops_per_launch": c["conv_flops_per_launch"],
             },
             "tower_tflops_end_to_end": (c["tower_evals"] * eng.tower_flops_per_eval()) / (c["tower_ms"] * 1e-3) / 1e12 if c["tower_ms"] > 0 else 0.0,
