@@ -105,7 +105,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torchrun the RCCL path is taken even with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -183,7 +183,7 @@ def main():
             },
             "tower_tflops_end_to_end": (c["tower_evals"] * eng.tower_flops_per_eval()) / (c["tower_ms"] * 1e-3) / 1e12 if c["tower_ms"] > 0 else 0.0,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only; at N>1 the other ranks would idle behind it
             out["cpu_baseline"] = cpu_baseline(H, args.blocks, args.channels, args.sims)
         print(json.dumps(out))
     eng.close()
