@@ -341,6 +341,60 @@ __device__ __forceinline__ void conv_epilogue(unsigned char *smem, const int *ro
     }
 }
 
+// Epilogue without an LDS round trip.  acc[i][j][r] is channel wc*64 + i*16 + (lane>>4)*4 + r of the
+// tile's point wr*128 + j*16 + (lane&15).  v_permlane16_swap of the registers of blocks i and i+1 leaves
+// every lane with 8 consecutive channels of one block (lane rows 0/2: block i, rows 1/3: block i+1), i.e.
+// one 16-byte piece of the NHWC row: bias, residual and ReLU are applied in fp32, rounded to bf16 once,
+// and stored.  Needs only `rowoff` from LDS, so no barrier is required before it.
+template <bool RESID>
+__device__ __forceinline__ void conv_epilogue_direct(const int *rowoff, f32x4 (&acc)[4][8], const float *__restrict__ bias,
+                                                     const bf16_t *__restrict__ R, bf16_t *__restrict__ Y, int M, int m0, int lane_in,
+                                                     int wr, int wc, const uint4 (&rpre)[8])
+{
+    constexpr int C = 256;
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));  // keeps the address arithmetic below from being hoisted above the K loop
+    const int q = lane >> 4, px = lane & 15;
+#pragma unroll
+    for (int ip = 0; ip < 2; ip++) {
+        const int ch = wc * 64 + (ip * 2 + (q & 1)) * 16 + (q >> 1) * 8;
+        const float4 b0 = *reinterpret_cast<const float4 *>(bias + ch), b1 = *reinterpret_cast<const float4 *>(bias + ch + 4);
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        long off[8];
+        bool ok[8];
+        uint4 rres[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int trow = wr * 128 + j * 16 + px;
+            ok[j] = m0 + trow < M;
+            off[j] = (long)rowoff[trow] * C + ch;
+            if (RESID) {  // rows past M are clamped to a valid row in rowoff, so the load needs no predicate
+                if (ip == 0) rres[j] = rpre[j];
+                else rres[j] = *reinterpret_cast<const uint4 *>(R + off[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ip * 2][j][r]), __float_as_uint(acc[ip * 2 + 1][j][r]), false, false);
+                v[r] = __uint_as_float(sw[0]);
+                v[4 + r] = __uint_as_float(sw[1]);
+            }
+            const unsigned rr[4] = {rres[j].x, rres[j].y, rres[j].z, rres[j].w};
+            unsigned out[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float lo = v[2 * k] + bb[2 * k], hi = v[2 * k + 1] + bb[2 * k + 1];
+                if (RESID) { lo += __uint_as_float(rr[k] << 16); hi += __uint_as_float(rr[k] & 0xffff0000u); }
+                out[k] = pack_bf16(fmaxf(lo, 0.f), fmaxf(hi, 0.f));
+            }
+            if (ok[j]) *reinterpret_cast<uint4 *>(Y + off[j]) = make_uint4(out[0], out[1], out[2], out[3]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Ping-pong variant of the kernel above.  Same tiles, LDS image, swizzle and epilogue; the
 // K loop is cut into half-steps (K = 32: 12 fragment reads, 32 MFMAs per wave) and the two
@@ -743,11 +797,31 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
         for (int i = i0; i < i1; i++)
 #pragma unroll
             for (int j = 0; j < 8; j++)
+#ifdef MFMA_BUILTIN
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+#else
+                // accumulate in place: tying the destination to the C operand keeps the register allocator from
+                // renaming the 128 accumulator registers from tap to tap (which costs spills inside the loop)
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[i]), "v"(xf[j]));
+#endif
     };
     // One MFMA interval: 32 MFMAs with this wave's share of the LDS-DMA slipped in after the first rows.
     // dw = how many half-steps ahead the weights are fetched (3 for group 0, 2 for group 1, which issues
     // one interval later); slab_tap = the tap at which the next chunk's slab is issued.
+    // residual pieces of channel blocks 0/1 in the epilogue's layout, fetched during the last intervals of the K loop
+#if defined(EPI_DIRECT)
+    constexpr int NPF = RESID ? 8 : 0;
+#else
+    constexpr int NPF = 0;
+#endif
+    uint4 rpre[8];
+    auto prefetch_resid = [&]() {
+        const int q = lane >> 4;
+        const unsigned ch = wc * 64 + (q & 1) * 16 + (q >> 1) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            rpre[j] = *reinterpret_cast<const uint4 *>(R + ((size_t)((unsigned)rowoff[wr * 128 + j * 16 + (lane & 15)] * C + ch)));
+    };
     auto mfma_interval = [&](int cc, int tap, int dw, int slab_tap) {
         __builtin_amdgcn_s_setprio(1);
         mfma_rows(0, 1);
@@ -755,6 +829,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
         const int tn = tap + dw;
         if (tn < 9) issue_w(cc, tn);
         else if (cc < 7) issue_w(cc + 1, tn - 9);
+        else if (NPF != 0 && tap == 6) prefetch_resid();
         __builtin_amdgcn_sched_barrier(0);
         mfma_rows(1, 2);
         __builtin_amdgcn_sched_barrier(0);
@@ -769,15 +844,20 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
     auto retire_g0 = [&](int cc, int tap) {  // end of group 0's MFMA interval of (cc, tap); issued up to W(h+3)
         if (cc < 7) { if (tap < 3) wait_vmcnt<4 + NSP>(); else wait_vmcnt<4>(); }
         else if (tap <= 5) wait_vmcnt<4>();
-        else if (tap == 6) wait_vmcnt<2>();
-        else wait_vmcnt<0>();
+        else if (tap == 6) wait_vmcnt<2 + NPF>();
+        else wait_vmcnt<NPF>();
     };
     auto retire_g1 = [&](int cc, int tap) {  // end of group 1's read interval of (cc, tap); issued up to W(h+2)
         if (cc < 7) { if (tap == 1 || tap == 2) wait_vmcnt<2 + NSP>(); else wait_vmcnt<2>(); }
         else if (tap <= 6) wait_vmcnt<2>();
-        else wait_vmcnt<0>();
+        else wait_vmcnt<NPF>();  // the prefetch was issued in the MFMA interval of (7, 6), one interval earlier
     };
 #define SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef ONE_BAR
+#define PP_MID() do {} while (0)
+#else
+#define PP_MID() PP_BAR()
+#endif
 
     issue_slab(0); issue_w(0, 0); issue_w(0, 1); issue_w(0, 2);
     wait_vmcnt<4>();
@@ -788,7 +868,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) {
                 rd_frags(cc, tap);
-                SB(); PP_BAR(); SB();
+                SB(); PP_MID(); SB();
                 mfma_interval(cc, tap, 3, 0);
                 retire_g0(cc, tap);
                 SB(); PP_BAR(); SB();
@@ -803,7 +883,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
                 // MFMAs of the previous half-step (its fragments were read one interval ago)
                 if (tap > 0) mfma_interval(cc, tap - 1, 3, 0);
                 else if (cc > 0) mfma_interval(cc - 1, 8, 3, 0);
-                SB(); PP_BAR(); SB();
+                SB(); PP_MID(); SB();
                 rd_frags(cc, tap);
                 retire_g1(cc, tap);
                 SB(); PP_BAR(); SB();
@@ -813,8 +893,24 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
         PP_BAR();
     }
 #undef SB
-    __syncthreads();
-    conv_epilogue<RESID>(smem, rowoff, acc, bias, R, Y, M, m0, wave, lane, wr, wc);
+#undef PP_MID
+#ifndef MFMA_BUILTIN
+    // the compiler does not know that the asm statements above are MFMAs, so it cannot insert the wait
+    // states an MFMA result needs before a vector ALU read: cover the longest case by hand
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+    // measured in the self-play bench: LDS-transpose epilogue 1225 TFLOP/s, register-swap epilogue 1193, mixed 1214
+#if defined(EPI_DIRECT)
+    constexpr bool kLdsEpilogue = false;
+#else
+    constexpr bool kLdsEpilogue = true;
+#endif
+    if (kLdsEpilogue) {
+        __syncthreads();
+        conv_epilogue<RESID>(smem, rowoff, acc, bias, R, Y, M, m0, wave, lane, wr, wc);
+    } else {
+        conv_epilogue_direct<RESID>(rowoff, acc, bias, R, Y, M, m0, lane, wr, wc, rpre);
+    }
 }
 
 // largest number of padded positions (incl. the one-row-plus-one halo on both sides) that a tile of
