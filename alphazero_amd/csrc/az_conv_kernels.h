@@ -699,12 +699,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {}
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 #endif
 
-template <bool RESID, int NSP>
+template <bool RESID, int NSP, int CIN = 256>
 __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
                                                                 const float *__restrict__ bias, const bf16_t *__restrict__ R,
                                                                 bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP, int npos)
 {
-    constexpr int C = 256, NH = 72, SLAB_BYTES = NSP * 128 * 64;
+    constexpr int C = 256, NCC = CIN / 32, SLAB_BYTES = NSP * 128 * 64;  // C output channels, NCC 32-channel input chunks
 #ifdef STAMP
     int stamp_i = 0;
 #endif
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int r = wave * 32 + q * 16 + frow;
-        woff[q] = r * 9 * C + ((fslot ^ (((r >> 2) & 1) << 1)) << 3);
+        woff[q] = r * 9 * CIN + ((fslot ^ (((r >> 2) & 1) << 1)) << 3);
     }
     // slab fill mapping: wave w fills pieces w + 8*i (16 rows each)
     int soff[NSP];
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
     for (int i = 0; i < NSP; i++) {
         const int sr = (wave + 8 * i) * 16 + frow;
         const int pos = min(pbase + sr, npos - 1);
-        soff[i] = pos * C + ((fslot ^ (((sr >> 2) & 1) << 1)) << 3);
+        soff[i] = pos * CIN + ((fslot ^ (((sr >> 2) & 1) << 1)) << 3);
     }
     unsigned char *const wfill = smem + (wave * 32) * 64;
     const int wrdo = (wc * 64 + (lane & 15)) * 64 + ((((lane >> 4)) ^ ((((lane & 15) >> 2) & 1) << 1)) << 4);
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
 #ifdef ABL_NODMA
         if (cc > 0) return;
 #endif
-        const int wofs = tap * C + cc * 32 + opaque0;
+        const int wofs = tap * CIN + cc * 32 + opaque0;
         unsigned char *dst = wfill + ((cc + tap) & 3) * 16384;
 #pragma unroll
         for (int q = 0; q < 2; q++) glds16(Wt + woff[q] + wofs, dst + q * 1024);
@@ -828,12 +828,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
         __builtin_amdgcn_sched_barrier(0);
         const int tn = tap + dw;
         if (tn < 9) issue_w(cc, tn);
-        else if (cc < 7) issue_w(cc + 1, tn - 9);
+        else if (cc < NCC - 1) issue_w(cc + 1, tn - 9);
         else if (NPF != 0 && tap == 6) prefetch_resid();
         __builtin_amdgcn_sched_barrier(0);
         mfma_rows(1, 2);
         __builtin_amdgcn_sched_barrier(0);
-        if (tap == slab_tap && cc < 7) issue_slab(cc + 1);
+        if (tap == slab_tap && cc < NCC - 1) issue_slab(cc + 1);
         __builtin_amdgcn_sched_barrier(0);
         mfma_rows(2, 4);
         __builtin_amdgcn_s_setprio(0);
@@ -842,13 +842,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
     // landed; `ahead` younger weight batches (2 glds each) may stay in flight, plus the NSP slab pieces
     // while they are younger than W(h+1).
     auto retire_g0 = [&](int cc, int tap) {  // end of group 0's MFMA interval of (cc, tap); issued up to W(h+3)
-        if (cc < 7) { if (tap < 3) wait_vmcnt<4 + NSP>(); else wait_vmcnt<4>(); }
+        if (cc < NCC - 1) { if (tap < 3) wait_vmcnt<4 + NSP>(); else wait_vmcnt<4>(); }
         else if (tap <= 5) wait_vmcnt<4>();
         else if (tap == 6) wait_vmcnt<2 + NPF>();
         else wait_vmcnt<NPF>();
     };
     auto retire_g1 = [&](int cc, int tap) {  // end of group 1's read interval of (cc, tap); issued up to W(h+2)
-        if (cc < 7) { if (tap == 1 || tap == 2) wait_vmcnt<2 + NSP>(); else wait_vmcnt<2>(); }
+        if (cc < NCC - 1) { if (tap == 1 || tap == 2) wait_vmcnt<2 + NSP>(); else wait_vmcnt<2>(); }
         else if (tap <= 6) wait_vmcnt<2>();
         else wait_vmcnt<NPF>();  // the prefetch was issued in the MFMA interval of (7, 6), one interval earlier
     };
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
     wait_vmcnt<4>();
     PP_BAR();
     if (wr == 0) {
-        for (int cc = 0; cc < 8; cc++) {
+        for (int cc = 0; cc < NCC; cc++) {
             asm volatile("" : "+s"(opaque0));
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) {
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
         }
         PP_BAR();
     } else {
-        for (int cc = 0; cc < 8; cc++) {
+        for (int cc = 0; cc < NCC; cc++) {
             asm volatile("" : "+s"(opaque0));
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) {
@@ -889,7 +889,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
                 SB(); PP_BAR(); SB();
             }
         }
-        mfma_interval(7, 8, 3, 0);
+        mfma_interval(NCC - 1, 8, 3, 0);
         PP_BAR();
     }
 #undef SB
@@ -927,6 +927,10 @@ static inline int conv_slab_span(int HW, int Wd, int PP)
     return worst;
 }
 
+// stem: 32 (zero padded) input channels -> 256, one 32-channel chunk, same kernel
+static inline bool launch_v5_stem(const bf16_t *X, const bf16_t *Wt, const float *bias, bf16_t *Y, int M, int HW, int Wd, int PP,
+                                  hipStream_t st = 0);
+
 static inline bool launch_v5(const bf16_t *X, const bf16_t *Wt, const float *bias, const bf16_t *R, bf16_t *Y, int M, int HW, int Wd,
                              int PP, hipStream_t st = 0)
 {
@@ -943,6 +947,18 @@ static inline bool launch_v5(const bf16_t *X, const bf16_t *Wt, const float *bia
         else hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 4>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos);
         return true;
     }
+    return false;
+}
+
+static inline bool launch_v5_stem(const bf16_t *X, const bf16_t *Wt, const float *bias, bf16_t *Y, int M, int HW, int Wd, int PP,
+                                  hipStream_t st)
+{
+    const int span = conv_slab_span(HW, Wd, PP);
+    const int npos = (M / HW) * PP;
+    dim3 g((M + 255) / 256), blk(512);
+    const bf16_t *R = nullptr;
+    if (span <= 3 * 128) { hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 3, 32>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos); return true; }
+    if (span <= 4 * 128) { hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 4, 32>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos); return true; }
     return false;
 }
 

@@ -46,31 +46,59 @@ static inline bf16_t h_f2bf(float f)
 }
 
 // ---------------------------------------------------------------------------
-// heads.  1x1 convolutions 256->2 (policy) and 256->1 (value) with folded BN + ReLU:
-// one wave per pixel, lanes across channels.  Output in NCHW-flatten order
-// (model.py:71-72 reshapes an NCHW tensor), i.e. hp[b][c*HW + pix].
+// heads.  1x1 convolutions 256->2 (policy) and 256->1 (value) with folded BN + ReLU.
+// Output in NCHW-flatten order (model.py:71-72 reshapes an NCHW tensor), i.e. hp[b][c*HW + pix].
+// HBM-bound: the last activation tensor is read once with 16-byte loads; LPP lanes share a board point
+// (8 bf16 / 4 fp32 channels per lane per load), partial sums are folded with xor-shuffles.
 // ---------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool ONEPASS>
 __global__ __launch_bounds__(256) void k_head_conv(const T *__restrict__ X, const float *__restrict__ wh, const float *__restrict__ bh,
-                                                   float *__restrict__ hp, float *__restrict__ hv, int HW, int Wd, int PP, int C)
+                                                   float *__restrict__ hp, float *__restrict__ hv, int HW, int Wd, int PP, int C, int LPP)
 {
+    constexpr int EPL = 16 / (int)sizeof(T);  // channels per 16-byte load
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int W2 = Wd + 2;
+    const int PPW = 64 / LPP;  // LPP lanes per point (a power of two), PPW points per wave pass
+    const int sub = lane / LPP, cl = lane % LPP;
     const float b0 = bh[0], b1 = bh[1], b2 = bh[2];
-    for (int pix = wave; pix < HW; pix += 4) {
-        int y = pix / Wd, x = pix - y * Wd;
+    float wreg[3][EPL];  // ONEPASS (C == LPP * EPL): this lane's weights stay in registers
+    if (ONEPASS) {
+#pragma unroll
+        for (int k = 0; k < EPL; k++) { wreg[0][k] = wh[cl * EPL + k]; wreg[1][k] = wh[C + cl * EPL + k]; wreg[2][k] = wh[2 * C + cl * EPL + k]; }
+    }
+    const int npass = (HW + 4 * PPW - 1) / (4 * PPW);
+    for (int it = 0; it < npass; it++) {
+        const int pix = (it * 4 + wave) * PPW + sub;
+        const bool ok = pix < HW;
+        const int pc = ok ? pix : HW - 1;
+        const int y = pc / Wd, x = pc - y * Wd;
         const T *row = X + ((size_t)b * PP + (y + 1) * W2 + (x + 1)) * C;
         float s0 = 0, s1 = 0, s2 = 0;
-        for (int c = lane; c < C; c += 64) {
-            float v;
-            if constexpr (sizeof(T) == 2) v = bf2f(row[c]); else v = row[c];
-            s0 = fmaf(v, wh[c], s0); s1 = fmaf(v, wh[C + c], s1); s2 = fmaf(v, wh[2 * C + c], s2);
-        }
+        for (int c0 = cl * EPL; c0 < C; c0 += LPP * EPL) {
+            float v[EPL];
+            if constexpr (sizeof(T) == 2) {
+                const uint4 u = *reinterpret_cast<const uint4 *>(row + c0);
+                const unsigned uu[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
+                for (int k = 0; k < 4; k++) { v[2 * k] = __uint_as_float(uu[k] << 16); v[2 * k + 1] = __uint_as_float(uu[k] & 0xffff0000u); }
+            } else {
+                const float4 f = *reinterpret_cast<const float4 *>(row + c0);
+                v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+            }
+#pragma unroll
+            for (int k = 0; k < EPL; k++) {
+                if (ONEPASS) {
+                    s0 = fmaf(v[k], wreg[0][k], s0); s1 = fmaf(v[k], wreg[1][k], s1); s2 = fmaf(v[k], wreg[2][k], s2);
+                } else {
+                    s0 = fmaf(v[k], wh[c0 + k], s0); s1 = fmaf(v[k], wh[C + c0 + k], s1); s2 = fmaf(v[k], wh[2 * C + c0 + k], s2);
+                }
+            }
+            if (ONEPASS) break;
+        }
+        for (int o = LPP >> 1; o > 0; o >>= 1) {
             s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64);
         }
-        if (lane == 0) {
+        if (cl == 0 && ok) {
             hp[(size_t)b * 2 * HW + pix] = fmaxf(s0 + b0, 0.0f);
             hp[(size_t)b * 2 * HW + HW + pix] = fmaxf(s1 + b1, 0.0f);
             hv[(size_t)b * HW + pix] = fmaxf(s2 + b2, 0.0f);
@@ -78,50 +106,117 @@ __global__ __launch_bounds__(256) void k_head_conv(const T *__restrict__ X, cons
     }
 }
 
-// policy FC + softmax, value FC256 + ReLU + FC1 + tanh; one workgroup per board
-__global__ __launch_bounds__(256) void k_head_fc(const float *__restrict__ hp, const float *__restrict__ hv,
+// policy FC + softmax, value FC256 + ReLU + FC1 + tanh.  FCB boards per workgroup of 6 waves share every weight
+// load; the reduction axis is split over the waves (each lane keeps 6 outputs x FCB boards) so that many
+// independent coalesced weight loads are in flight, and the wave partials are folded through LDS.
+#define FCB 4
+__global__ __launch_bounds__(384) void k_head_fc(const float *__restrict__ hp, const float *__restrict__ hv,
                                                  const float *__restrict__ wp, const float *__restrict__ bp,
                                                  const float *__restrict__ w1, const float *__restrict__ b1,
                                                  const float *__restrict__ w2, const float *__restrict__ b2,
-                                                 float *__restrict__ priors, float *__restrict__ values, int HW, int O)
+                                                 float *__restrict__ priors, float *__restrict__ values, int HW, int O, int B)
 {
-    __shared__ float sp[2 * 361];
-    __shared__ float sv[361];
-    __shared__ float red[256];
-    __shared__ float logit[384];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < 2 * HW; i += 256) sp[i] = hp[(size_t)b * 2 * HW + i];
-    for (int i = tid; i < HW; i += 256) sv[i] = hv[(size_t)b * HW + i];
-    __syncthreads();
-    float lmax = -INFINITY;
-    for (int o = tid; o < O; o += 256) {
-        float s = 0.0f;
-        for (int j = 0; j < 2 * HW; j++) s = fmaf(sp[j], wp[(size_t)j * O + o], s);
-        s += bp[o];
-        logit[o] = s;
-        lmax = fmaxf(lmax, s);
+    __shared__ float sp[FCB][2 * 361 + 2];
+    __shared__ float sv[FCB][361 + 3];
+    __shared__ float part[6][FCB][384];
+    __shared__ float logit[FCB][384];
+    __shared__ float vred[FCB][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bb = blockIdx.x * FCB;
+    for (int q = 0; q < FCB; q++) {
+        const int b = min(bb + q, B - 1);
+        for (int i = tid; i < 2 * HW; i += 384) sp[q][i] = hp[(size_t)b * 2 * HW + i];
+        for (int i = tid; i < HW; i += 384) sv[q][i] = hv[(size_t)b * HW + i];
     }
-    red[tid] = lmax;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]); __syncthreads(); }
-    const float mx = red[0];
+    {   // policy logits
+        const int J = 2 * HW, per = (J + 5) / 6, j0 = wave * per, j1 = min(J, j0 + per);
+        int oo[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) oo[k] = min(lane + 64 * k, O - 1);
+        float acc[FCB][6] = {};
+#pragma unroll 4
+        for (int j = j0; j < j1; j++) {
+            float wv[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) wv[k] = wp[(size_t)j * O + oo[k]];
+#pragma unroll
+            for (int q = 0; q < FCB; q++) {
+                const float sj = sp[q][j];
+#pragma unroll
+                for (int k = 0; k < 6; k++) acc[q][k] = fmaf(sj, wv[k], acc[q][k]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < FCB; q++)
+#pragma unroll
+            for (int k = 0; k < 6; k++) part[wave][q][lane + 64 * k] = acc[q][k];
+    }
     __syncthreads();
-    float lsum = 0.0f;
-    for (int o = tid; o < O; o += 256) { float e = expf(logit[o] - mx); logit[o] = e; lsum += e; }
-    red[tid] = lsum;
+    if (tid < O) {
+        const float bo = bp[tid];
+#pragma unroll
+        for (int q = 0; q < FCB; q++) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 6; w++) s += part[w][q][tid];
+            logit[q][tid] = s + bo;
+        }
+    }
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-    const float tot = red[0];
+    if (wave < FCB && bb + wave < B) {  // softmax of one board per wave
+        float lv[6], mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int o = lane + 64 * k;
+            lv[k] = o < O ? logit[wave][o] : -INFINITY;
+            mx = fmaxf(mx, lv[k]);
+        }
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) { lv[k] = lane + 64 * k < O ? expf(lv[k] - mx) : 0.0f; sum += lv[k]; }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            if (lane + 64 * k < O) priors[(size_t)(bb + wave) * O + lane + 64 * k] = lv[k] / sum;
+    }
+    __syncthreads();  // `part` is reused below
+    {   // value hidden layer: 256 outputs, 4 per lane
+        const int per = (HW + 5) / 6, j0 = wave * per, j1 = min(HW, j0 + per);
+        float acc[FCB][4] = {};
+#pragma unroll 4
+        for (int j = j0; j < j1; j++) {
+            float wv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) wv[k] = w1[(size_t)j * 256 + lane + 64 * k];
+#pragma unroll
+            for (int q = 0; q < FCB; q++) {
+                const float sj = sv[q][j];
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc[q][k] = fmaf(sj, wv[k], acc[q][k]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < FCB; q++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) part[wave][q][lane + 64 * k] = acc[q][k];
+    }
     __syncthreads();
-    for (int o = tid; o < O; o += 256) priors[(size_t)b * O + o] = logit[o] / tot;
-    // value head
-    float h = 0.0f;
-    for (int j = 0; j < HW; j++) h = fmaf(sv[j], w1[(size_t)j * 256 + tid], h);
-    h = fmaxf(h + b1[tid], 0.0f);
-    red[tid] = h * w2[tid];
+    if (tid < 256) {
+        const float b1t = b1[tid], w2t = w2[tid];
+#pragma unroll
+        for (int q = 0; q < FCB; q++) {
+            float h = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 6; w++) h += part[w][q][tid];
+            float v = fmaxf(h + b1t, 0.0f) * w2t;
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) vred[q][wave] = v;
+        }
+    }
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-    if (tid == 0) values[b] = tanhf(red[0] + b2[0]);
+    if (tid < FCB && bb + tid < B) values[bb + tid] = tanhf(vred[tid][0] + vred[tid][1] + vred[tid][2] + vred[tid][3] + b2[0]);
 }
 
 // ---------------------------------------------------------------------------
@@ -255,6 +350,7 @@ void launch_conv<bf16_t>(const Tower *t, const bf16_t *X, const bf16_t *Wt, cons
         else hipLaunchKernelGGL((k_conv3x3_c256_bf16<false>), g2, b2, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP);
         return;
     }
+    if (cin == CIN0 && CIN0 == 32 && t->C == 256 && !R && launch_v5_stem(X, Wt, bias, Y, M, t->HW, t->W, t->PP, st)) return;
     if (cin == CIN0)
         hipLaunchKernelGGL((k_conv3x3_bf16<32, false>), grid, block, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C);
     else if (R)
@@ -292,10 +388,19 @@ static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float
         if (t->profile) hipEventRecord(t->evs[t->evs_used++], st);
         T *tmp = X; X = Y; Y = tmp;
     }
-    hipLaunchKernelGGL((k_head_conv<T>), dim3(B), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, t->hp, t->hv, t->HW, t->W,
-                       t->PP, (int)C);
-    hipLaunchKernelGGL(k_head_fc, dim3(B), dim3(256), 0, st, t->hp, t->hv, t->w_pfc, t->b_pfc, t->w_v1, t->b_v1, t->w_v2, t->b_v2,
-                       priors, values, t->HW, t->O);
+    {
+        const int chunks = (int)C / (16 / (int)sizeof(T));  // 16-byte pieces per board point
+        int lpp = 64;
+        while (chunks % lpp) lpp >>= 1;                     // largest power of two <= 64 dividing it
+        if (chunks == lpp)
+            hipLaunchKernelGGL((k_head_conv<T, true>), dim3(B), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, t->hp, t->hv, t->HW,
+                               t->W, t->PP, (int)C, lpp);
+        else
+            hipLaunchKernelGGL((k_head_conv<T, false>), dim3(B), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, t->hp, t->hv, t->HW,
+                               t->W, t->PP, (int)C, lpp);
+    }
+    hipLaunchKernelGGL(k_head_fc, dim3((B + FCB - 1) / FCB), dim3(384), 0, st, t->hp, t->hv, t->w_pfc, t->b_pfc, t->w_v1, t->b_v1, t->w_v2,
+                       t->b_v2, priors, values, t->HW, t->O, B);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
