@@ -74,7 +74,14 @@ def cpu_baseline(H, num_blocks, channels, sims, budget_s=20.0):
     tree.search(st, n, True, cb, rng)
     dt = time.perf_counter() - t0
     sims_per_s = n_eval[0] / dt
+    ref = None
+    try:  # the reference's own Python search timed in the build container (it cannot run on the GPU box): data fixture
+        with open(os.path.join(ROOT, "tests", "golden", "cpu_baseline_reference.json")) as f:
+            ref = json.load(f)
+    except OSError:
+        pass
     return {
+        "reference_python_in_build_container": ref,
         "value": sims_per_s / (sims + 1), "unit": "moves/s", "sims_per_sec": sims_per_s, "cores": cores, "kind": "port",
         "sample": "first %d simulations of one Go %dx%d game's first search (%d-block %d-ch fp32 net on CPU, "
                   "one leaf per evaluation); moves/s = sims/s / %d" % (n_eval[0], H, H, num_blocks, channels, sims + 1),

@@ -1,0 +1,93 @@
+"""TEST / MEASUREMENT INFRASTRUCTURE - NOT PRODUCT CODE.
+
+Times the reference's own Python self-play search (/root/reference, read-only; this container only)
+on the headline workload - Go 19x19, MCTSearch._calc_move from the empty board - and writes the result
+as a data fixture, tests/golden/cpu_baseline_reference.json, that bench.py quotes beside the number it
+measures with the C port on the GPU box (the reference itself cannot travel there).
+
+Two evaluators, both honouring the reference's evaluator contract (eval(state) -> ([(action, prob)], value)):
+  * "uniform"  - no network at all: isolates rules + search + feature cost of the reference
+  * "torch_fp32" - the fp32 PyTorch-CPU restatement of the dual-head ResNet (TensorFlow is absent),
+                   one leaf per call, as a single reference game process sees its evaluator
+
+    python oracle/ref_cpu_baseline.py [--sims 200] [--net-sims 40]
+"""
+import argparse
+import json
+import os
+import platform
+import sys
+import time
+
+import numpy as np
+import yaml
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, ".."))
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+np.int = int
+np.float = float
+_yl = yaml.load
+yaml.load = lambda f, Loader=yaml.SafeLoader: _yl(f, Loader=Loader)
+
+import AlphaZero.env.go as go  # noqa: E402
+import AlphaZero.processing.state_converter as sc  # noqa: E402
+import AlphaZero.search.mcts as mcts  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sims", type=int, default=200)
+    ap.add_argument("--net-sims", type=int, default=40)
+    ap.add_argument("--blocks", type=int, default=20)
+    args = ap.parse_args()
+    import torch
+    from alphazero_amd.network.model import random_net
+    from oracle import tower_ref
+
+    with open(os.path.join(REF, "AlphaZero", "config", "go.yaml")) as f:
+        cfg = yaml.load(f)
+    H = W = 19
+    O = H * W + 1
+    s2t = sc.StateTensorConverter(cfg)
+    t2a = sc.TensorActionConverter(cfg)
+
+    def uniform_eval(state):
+        s2t.state_to_tensor(state)  # the reference's evaluator always converts the state
+        p = np.full(O, 1.0 / O, dtype=np.float32)
+        return t2a.tensor_to_action(p), np.float32(0.0)
+
+    net = random_net(H, W, O, args.blocks, 256, seed=0)
+    sd = net.state_dict()
+    threads = torch.get_num_threads()
+
+    def torch_eval(state):
+        x = torch.from_numpy(np.ascontiguousarray(s2t.state_to_tensor(state))).float()
+        p, v = tower_ref.forward(sd, x, args.blocks)
+        return t2a.tensor_to_action(p[0].numpy()), np.float32(v[0])
+
+    out = {"workload": "Go 19x19, MCTSearch._calc_move from the empty board, Dirichlet noise on, 8 transforms",
+           "host": {"cpu": platform.processor() or platform.machine(), "cores_visible": os.cpu_count(), "torch_threads": threads},
+           "measured_with": "oracle/ref_cpu_baseline.py (reference Python search, NumPy %s)" % np.__version__}
+    for name, ev, n in (("uniform", uniform_eval, args.sims), ("torch_fp32", torch_eval, args.net_sims)):
+        np.random.seed(0)
+        search = mcts.MCTSearch(ev, cfg, max_playout=n)
+        st = go.GameState(size=19)
+        t0 = time.perf_counter()
+        search.calc_move_with_probs(st, dirichlet=True)
+        dt = time.perf_counter() - t0
+        sims = n + 1
+        out[name] = {"sims": sims, "seconds": dt, "sims_per_sec": sims / dt, "moves_per_sec_at_800": sims / dt / 801.0,
+                     "processes": 1}
+        print(name, out[name])
+    path = os.path.join(HERE, "..", "tests", "golden", "cpu_baseline_reference.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()
