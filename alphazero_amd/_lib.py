@@ -87,6 +87,8 @@ SIGNATURES = {
     "az_rng_cursor": (_I, [_P, _I, _P, _P, _P]),
     "az_tower_blob_floats": (C.c_size_t, [_P]),
     "az_tower_load_weights": (_I, [_P, _P, C.c_size_t]),
+    "az_tower_load_weights_net": (_I, [_P, _I, _P, C.c_size_t]),
+    "az_match_assign": (_I, [_P, _P, _I, _P]),
     "az_tower_forward": (_I, [_P, _P, _I, _P, _P]),
     "az_tower_flops_per_eval": (C.c_double, [_P]),
     "az_tower_profile": (_I, [_P, _I]),

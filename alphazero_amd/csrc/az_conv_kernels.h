@@ -32,10 +32,11 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
 // int8 planes (B,17,H,W) -> NHWC with halo, CIN0 channels (17 real + zeros)
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ void k_planes_to_nhwc(const int8_t *planes, T *X0, int H, int W)
+__global__ void k_planes_to_nhwc(const int8_t *planes, T *X0, int H, int W, const int32_t *__restrict__ rows)
 {
+    // board b of the batch is row rows[b] of `planes` (rows == nullptr: row b)
     const int b = blockIdx.x, HW = H * W, PP = (H + 2) * (W + 2);
-    const int8_t *src = planes + (size_t)b * 17 * HW;
+    const int8_t *src = planes + (size_t)(rows ? rows[b] : b) * 17 * HW;
     for (int idx = threadIdx.x; idx < HW * CIN0; idx += blockDim.x) {
         int pix = idx / CIN0, c = idx - pix * CIN0;
         int y = pix / W, x = pix - y * W;

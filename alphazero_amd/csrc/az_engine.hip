@@ -27,6 +27,10 @@ struct az_engine {
     std::vector<void *> allocs;
     std::string error;
     Tower *tower = nullptr;
+    // two-network matches: second weight set, which network moves first in each slot, per-network leaf lists
+    Tower *tower2 = nullptr;
+    bool two_nets = false;
+    int32_t *net_first = nullptr, *net_rows = nullptr, *net_cnt = nullptr;  // [G], [2][G], [2]
     // staging
     int32_t *st_a = nullptr, *st_b = nullptr, *st_c = nullptr, *st_d = nullptr, *st_e = nullptr;  // [max(G,64)] each
     uint8_t *st_bytes = nullptr;   // [G * max(O, 17*NC)]
@@ -92,6 +96,7 @@ extern "C" void az_engine_destroy(az_engine *h)
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->tower) tower_destroy(h->tower);
+    if (h->tower2) tower_destroy(h->tower2);
     for (void *p : h->allocs) hipFree(p);
     for (void *p : h->rng_bufs) if (p) hipFree(p);
     for (int i = 0; i < 4; i++) if (h->ev[i]) hipEventDestroy(h->ev[i]);
@@ -176,6 +181,8 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     const size_t stn = std::max(G, 64);
     ok = ok && (h->st_a = dalloc<int32_t>(h, stn)) && (h->st_b = dalloc<int32_t>(h, stn)) &&
          (h->st_c = dalloc<int32_t>(h, stn)) && (h->st_d = dalloc<int32_t>(h, stn)) && (h->st_e = dalloc<int32_t>(h, stn));
+    ok = ok && (h->net_first = dalloc<int32_t>(h, G)) && (h->net_rows = dalloc<int32_t>(h, 2 * (size_t)G)) &&
+         (h->net_cnt = dalloc<int32_t>(h, 2));
     h->st_bytes_n = (size_t)G * std::max(O, 17 * NC);
     ok = ok && (h->st_bytes = dalloc<uint8_t>(h, h->st_bytes_n));
     if (!ok) {
@@ -432,6 +439,24 @@ static int evaluate(az_engine *h, const float *priors, const float *values)
     }
     if (!h->tower || !tower_ready(h->tower)) return set_err(h, AZ_ERR_NO_WEIGHTS, "no tower weights loaded and no priors injected");
     std::string terr;
+    if (h->two_nets) {
+        if (!h->tower2 || !tower_ready(h->tower2)) return set_err(h, AZ_ERR_NO_WEIGHTS, "two-network match: network 1 has no weights");
+        hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, h->stream, h->D, (const int32_t *)h->net_first, h->net_rows, h->net_cnt);
+        int32_t cnt[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(cnt, h->net_cnt, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        Tower *tw[2] = {h->tower, h->tower2};
+        for (int net = 0; net < 2; net++) {
+            if (cnt[net] == 0) continue;
+            if (tower_forward(tw[net], h->D.planes, cnt[net], h->D.priors, h->D.values, h->stream, terr, h->net_rows + (size_t)net * G) != 0) {
+                h->error = "tower: " + terr;
+                return AZ_ERR_HIP;
+            }
+            h->tower_calls++;
+            h->tower_evals += cnt[net];
+        }
+        return AZ_OK;
+    }
     if (tower_forward(h->tower, h->D.planes, G, h->D.priors, h->D.values, h->stream, terr) != 0) {
         h->error = "tower: " + terr;
         return AZ_ERR_HIP;
@@ -698,6 +723,40 @@ extern "C" int az_tower_load_weights(az_engine *h, const float *blob, size_t n)
     HIPCHK(hipSetDevice(h->cfg.device));
     std::string terr;
     if (tower_load(h->tower, blob, n, h->stream, terr) != 0) { h->error = "tower: " + terr; return AZ_ERR_ARG; }
+    return AZ_OK;
+}
+
+extern "C" int az_tower_load_weights_net(az_engine *h, int32_t net, const float *blob, size_t n)
+{
+    if (!h || !blob || net < 0 || net > 1) return AZ_ERR_ARG;
+    if (net == 0) return az_tower_load_weights(h, blob, n);
+    if (!h->tower) return set_err(h, AZ_ERR_ARG, "engine was created with num_blocks = 0 (no tower)");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    std::string terr;
+    if (!h->tower2) {
+        const az_config &c = h->cfg;
+        h->tower2 = tower_create(c.board_height, c.board_width, h->D.geo.O, c.num_blocks, c.channels > 0 ? c.channels : 256, c.tower_dtype,
+                                 h->D.G, terr);
+        if (!h->tower2) { h->error = "tower: " + terr; return AZ_ERR_HIP; }
+    }
+    if (tower_load(h->tower2, blob, n, h->stream, terr) != 0) { h->error = "tower: " + terr; return AZ_ERR_ARG; }
+    return AZ_OK;
+}
+
+extern "C" int az_match_assign(az_engine *h, const int32_t *slots, int32_t n, const int32_t *net_of_first)
+{
+    if (!h || n < 0) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (n == 0) { h->two_nets = false; return AZ_OK; }
+    int rc = check_slots(h, slots, n);
+    if (rc) return rc;
+    if (!net_of_first) return set_err(h, AZ_ERR_ARG, "null net_of_first");
+    for (int i = 0; i < n; i++) {
+        if (net_of_first[i] < 0 || net_of_first[i] > 1) return set_err(h, AZ_ERR_ARG, "network index must be 0 or 1");
+        HIPCHK(hipMemcpy(h->net_first + slots[i], net_of_first + i, sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    h->two_nets = true;
     return AZ_OK;
 }
 

@@ -676,3 +676,41 @@ __global__ __launch_bounds__(64) void k_choose(Dev D, int g, int side, double u,
     int mv = dev_choose(D, L, 2 * g + side, u, &n);
     if (lane_id() == 0) out[0] = mv;
 }
+
+// ---------------------------------------------------------------------------
+// Two-network matches (train/parallel/evaluator.py:81-84: Game(chal, best) or Game(best, chal)).
+// Splits the round's valid leaves by the network that owns the searching tree: side s of slot g is
+// evaluated by network net_of_first[g] ^ s.  One workgroup; each list keeps slot order.
+// rows[net * G + i] = i-th slot of that network, counts[net] = length.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_partition(Dev D, const int32_t *__restrict__ net_of_first, int32_t *__restrict__ rows,
+                                                    int32_t *__restrict__ counts)
+{
+    __shared__ int wtot[2][16];
+    __shared__ int base[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 2) base[tid] = 0;
+    __syncthreads();
+    for (int g0 = 0; g0 < D.G; g0 += 1024) {
+        const int g = g0 + tid;
+        int net = -1;
+        if (g < D.G && D.leaf_valid[g]) net = (net_of_first[g] ^ D.side[g]) & 1;
+        const unsigned long long m0 = __ballot(net == 0), m1 = __ballot(net == 1);
+        if (lane == 0) { wtot[0][wave] = __popcll(m0); wtot[1][wave] = __popcll(m1); }
+        __syncthreads();
+        if (net >= 0) {
+            int off = base[net];
+            for (int w = 0; w < wave; w++) off += wtot[net][w];
+            off += __popcll((net ? m1 : m0) & ((1ull << lane) - 1ull));
+            rows[(size_t)net * D.G + off] = g;
+        }
+        __syncthreads();
+        if (tid < 2) {
+            int t = 0;
+            for (int w = 0; w < 16; w++) t += wtot[tid][w];
+            base[tid] += t;
+        }
+        __syncthreads();
+    }
+    if (tid < 2) counts[tid] = base[tid];
+}

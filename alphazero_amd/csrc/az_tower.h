@@ -13,9 +13,10 @@ size_t tower_blob_floats(const Tower *t);
 // host float32 blob (layout: alphazero_amd/network/model.py) -> device weights in the compute dtype
 int tower_load(Tower *t, const float *host_blob, size_t n_floats, hipStream_t st, std::string &err);
 bool tower_ready(const Tower *t);
-// planes_dev int8 (B,17,H,W); priors_dev (B,O), values_dev (B) float32
+// planes_dev int8 (*,17,H,W); priors_dev (*,O), values_dev (*) float32.  Board b of the batch of B is row
+// rows_dev[b] of those arrays (rows_dev == nullptr: row b), so a subset of a larger leaf batch can be evaluated in place.
 int tower_forward(Tower *t, const int8_t *planes_dev, int B, float *priors_dev, float *values_dev, hipStream_t st,
-                  std::string &err);
+                  std::string &err, const int32_t *rows_dev = nullptr);
 double tower_flops_per_eval(const Tower *t);
 // names/durations of the dominant kernel for the roofline line
 double tower_conv_flops_per_launch(const Tower *t, int B);

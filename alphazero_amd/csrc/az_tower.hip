@@ -114,7 +114,8 @@ __global__ __launch_bounds__(384) void k_head_fc(const float *__restrict__ hp, c
                                                  const float *__restrict__ wp, const float *__restrict__ bp,
                                                  const float *__restrict__ w1, const float *__restrict__ b1,
                                                  const float *__restrict__ w2, const float *__restrict__ b2,
-                                                 float *__restrict__ priors, float *__restrict__ values, int HW, int O, int B)
+                                                 float *__restrict__ priors, float *__restrict__ values, int HW, int O, int B,
+                                                 const int32_t *__restrict__ rows)
 {
     __shared__ float sp[FCB][2 * 361 + 2];
     __shared__ float sv[FCB][361 + 3];
@@ -177,9 +178,10 @@ __global__ __launch_bounds__(384) void k_head_fc(const float *__restrict__ hp, c
 #pragma unroll
         for (int k = 0; k < 6; k++) { lv[k] = lane + 64 * k < O ? expf(lv[k] - mx) : 0.0f; sum += lv[k]; }
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const int orow = rows ? rows[bb + wave] : bb + wave;  // batch board -> row of the caller's arrays
 #pragma unroll
         for (int k = 0; k < 6; k++)
-            if (lane + 64 * k < O) priors[(size_t)(bb + wave) * O + lane + 64 * k] = lv[k] / sum;
+            if (lane + 64 * k < O) priors[(size_t)orow * O + lane + 64 * k] = lv[k] / sum;
     }
     __syncthreads();  // `part` is reused below
     {   // value hidden layer: 256 outputs, 4 per lane
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(384) void k_head_fc(const float *__restrict__ hp, c
         }
     }
     __syncthreads();
-    if (tid < FCB && bb + tid < B) values[bb + tid] = tanhf(vred[tid][0] + vred[tid][1] + vred[tid][2] + vred[tid][3] + b2[0]);
+    if (tid < FCB && bb + tid < B) values[rows ? rows[bb + tid] : bb + tid] = tanhf(vred[tid][0] + vred[tid][1] + vred[tid][2] + vred[tid][3] + b2[0]);
 }
 
 // ---------------------------------------------------------------------------
@@ -372,11 +374,11 @@ void launch_conv<float>(const Tower *t, const float *X, const float *Wt, const f
 }
 
 template <typename T>
-static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float *values, hipStream_t st)
+static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float *values, hipStream_t st, const int32_t *rows)
 {
     const size_t C = t->C;
     T *X0 = (T *)t->X0, *X = (T *)t->X, *Tm = (T *)t->T, *Y = (T *)t->Y;
-    hipLaunchKernelGGL((k_planes_to_nhwc<T>), dim3(B), dim3(256), 0, st, planes, X0, t->H, t->W);
+    hipLaunchKernelGGL((k_planes_to_nhwc<T>), dim3(B), dim3(256), 0, st, planes, X0, t->H, t->W, rows);
     launch_conv<T>(t, X0, (const T *)t->w_stem, t->b_stem, (const T *)nullptr, X, B, CIN0, st);
     for (int l = 0; l < t->NB; l++) {
         const T *w1 = (const T *)t->w_conv + (size_t)(2 * l) * C * 9 * C;
@@ -400,17 +402,18 @@ static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float
                                t->W, t->PP, (int)C, lpp);
     }
     hipLaunchKernelGGL(k_head_fc, dim3((B + FCB - 1) / FCB), dim3(384), 0, st, t->hp, t->hv, t->w_pfc, t->b_pfc, t->w_v1, t->b_v1, t->w_v2,
-                       t->b_v2, priors, values, t->HW, t->O, B);
+                       t->b_v2, priors, values, t->HW, t->O, B, rows);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int tower_forward(Tower *t, const int8_t *planes_dev, int B, float *priors_dev, float *values_dev, hipStream_t st, std::string &err)
+int tower_forward(Tower *t, const int8_t *planes_dev, int B, float *priors_dev, float *values_dev, hipStream_t st, std::string &err,
+                  const int32_t *rows_dev)
 {
     if (!t->ready) { err = "weights not loaded"; return -1; }
     if (B < 1 || B > t->maxB) { err = "batch exceeds the tower's activation buffers"; return -1; }
     t->evs_used = 0;
-    int rc = t->dtype == 1 ? forward_t<bf16_t>(t, planes_dev, B, priors_dev, values_dev, st)
-                           : forward_t<float>(t, planes_dev, B, priors_dev, values_dev, st);
+    int rc = t->dtype == 1 ? forward_t<bf16_t>(t, planes_dev, B, priors_dev, values_dev, st, rows_dev)
+                           : forward_t<float>(t, planes_dev, B, priors_dev, values_dev, st, rows_dev);
     if (rc) err = std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError());
     return rc;
 }

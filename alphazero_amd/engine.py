@@ -216,9 +216,19 @@ class Engine:
     def tower_blob_floats(self):
         return self._L.az_tower_blob_floats(self._h)
 
-    def tower_load(self, blob):
+    def tower_load(self, blob, net=0):
         b = np.ascontiguousarray(blob, np.float32)
-        self._ck(self._L.az_tower_load_weights(self._h, b.ctypes.data, b.size))
+        if net == 0:
+            self._ck(self._L.az_tower_load_weights(self._h, b.ctypes.data, b.size))
+        else:
+            self._ck(self._L.az_tower_load_weights_net(self._h, int(net), b.ctypes.data, b.size))
+
+    def match_assign(self, slots, net_of_first):
+        """Two-network match: in slots[i] the side moving first is evaluated by network net_of_first[i]
+        (evaluator.py:81-84).  Empty `slots` switches back to one network."""
+        s = np.ascontiguousarray(slots, np.int32)
+        nf = np.ascontiguousarray(net_of_first, np.int32)
+        self._ck(self._L.az_match_assign(self._h, s.ctypes.data if s.size else None, s.size, nf.ctypes.data if nf.size else None))
 
     def tower_forward(self, planes):
         x = np.ascontiguousarray(planes, np.int8)

@@ -119,3 +119,79 @@ class BatchedSelfplay:
                 out.append(history_arrays(self._replay, tr["moves"], tr["visits"], tr["winner"]))
             self._sync_weights()
         return out[:num_games]
+
+
+def gating_colors(num_games):
+    """Colour of the challenger in each game of a gating match: alternating, Black first
+    (train/parallel/evaluator.py:114-115)."""
+    return [1, -1] * (num_games // 2) + [1] * (num_games % 2)
+
+
+def gating_verdict(winners, colors_of_new):
+    """(win_counter, num_not_tie, accepted) by the rule of train/parallel/evaluator.py:86-89,122:
+    a game counts for the challenger when its winner equals the challenger's colour, draws are left
+    out of the denominator, and the challenger is accepted iff wins > int(0.55 * num_not_tie)."""
+    win_counter = sum(1 for w, c in zip(winners, colors_of_new) if w == c)
+    num_not_tie = sum(1 for w in winners if w is not None and w != 0)
+    return win_counter, num_not_tie, win_counter > int(0.55 * num_not_tie)
+
+
+class BatchedMatch:
+    """Gating match between a challenger and the best model, all games concurrently on one GPU with both
+    weight sets resident: the role of Evaluator.run + eval_wrapper (train/parallel/evaluator.py:70-126),
+    i.e. Game(chal, best, ...) when the challenger is Black and Game(best, chal, ...) otherwise.
+
+    ext_config is the reference's `evaluator` section: {'num_games', 'num_worker', 'gameplay': {...}};
+    `n_parallel` (default: every game at once) replaces num_worker as the concurrency limit."""
+
+    def __init__(self, nn_eval_chal, nn_eval_best, game_config, ext_config, n_parallel=None, seed=0, device=0):
+        self.nn_eval_chal, self.nn_eval_best = nn_eval_chal, nn_eval_best
+        self.game_config, self.ext_config = game_config, ext_config
+        self.num_games = ext_config['num_games']
+        self.n_parallel = min(self.num_games, n_parallel or self.num_games)
+        self.seed, self.device = seed, device
+        self.eng = None
+
+    def _engine(self):
+        if self.eng is None:
+            gp = self.ext_config['gameplay']
+            ev = self.nn_eval_chal
+            self.eng = Engine(n_slots=self.n_parallel, max_playout=gp['player']['max_playout'],
+                              dirichlet_before=gp['dirichlet_before'], max_turn=gp['max_turn'], record_trajectories=True,
+                              seed=self.seed, num_blocks=ev.num_blocks, channels=ev.channels, tower_dtype=ev.dtype,
+                              device=self.device, **game_config_to_engine_kwargs(self.game_config))
+        return self.eng
+
+    def run(self, rounds_per_poll=64):
+        """Plays ext_config['num_games'] games; returns a dict with the reference's counters
+        (win_counter, num_not_tie), the acceptance decision and the per-game winners / colours."""
+        eng = self._engine()
+        eng.tower_load(self.nn_eval_chal._tower_blob, net=0)   # network 0 = challenger
+        eng.tower_load(self.nn_eval_best._tower_blob, net=1)
+        colors = gating_colors(self.num_games)
+        winners = [None] * self.num_games
+        game_of_slot = list(range(self.n_parallel))
+        next_game = self.n_parallel
+        eng.selfplay_start()
+        eng.match_assign(list(range(self.n_parallel)), [0 if colors[g] == 1 else 1 for g in game_of_slot])
+        finished = 0
+        while finished < self.num_games:
+            eng.selfplay_run(rounds_per_poll)
+            _, done = eng.selfplay_status()
+            for s in np.flatnonzero(done):
+                s = int(s)
+                if game_of_slot[s] is None:
+                    continue
+                more = next_game < self.num_games
+                tr = eng.trajectory_pop(s, restart=more)
+                winners[game_of_slot[s]] = tr["winner"]
+                finished += 1
+                if more:
+                    game_of_slot[s] = next_game
+                    eng.match_assign([s], [0 if colors[next_game] == 1 else 1])
+                    next_game += 1
+                else:
+                    game_of_slot[s] = None
+        win_counter, num_not_tie, accepted = gating_verdict(winners, colors)
+        return {"win_counter": win_counter, "num_not_tie": num_not_tie, "win_rate": win_counter / (num_not_tie + 1e-9),
+                "accepted": accepted, "winners": winners, "colors_of_new": colors}

@@ -180,6 +180,13 @@ int az_rng_cursor(az_engine *h, int32_t slot, int64_t *i_tids, int64_t *i_etas, 
 size_t az_tower_blob_floats(az_engine *h);      /* float32 count of the folded-weight blob */
 /* folded float32 weights, layout documented in alphazero_amd/network/model.py */
 int az_tower_load_weights(az_engine *h, const float *blob, size_t n_floats);
+/* Gating matches between two weight sets (train/parallel/evaluator.py:70-98: Game(nn_eval_chal, nn_eval_best, ...) or
+ * the two swapped).  Network 0 is the one az_tower_load_weights fills; network 1 is created on first load.
+ * az_match_assign: in slot slots[i] the side that moves first (player_1, Black) is evaluated by network
+ * net_of_first[i] (0/1), the other side by the other network; from then on az_selfplay_run / az_selfplay_finish
+ * with NULL priors route every leaf to the network owning the searching tree.  n = 0 returns to one network. */
+int az_tower_load_weights_net(az_engine *h, int32_t net, const float *blob, size_t n_floats);
+int az_match_assign(az_engine *h, const int32_t *slots, int32_t n, const int32_t *net_of_first);
 /* x int8 (B,17,H,W) host; out_p (B,O), out_v (B) float32 host */
 int az_tower_forward(az_engine *h, const int8_t *planes, int32_t B, float *out_p, float *out_v);
 double az_tower_flops_per_eval(az_engine *h);

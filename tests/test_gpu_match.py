@@ -1,0 +1,83 @@
+"""Two-network (gating) matches on the device: the batched path that routes every leaf to the network
+owning the searching tree must reproduce, bit for bit, the same engine driven leaf by leaf with priors
+computed separately by each network (the reference's Game(chal, best) / Game(best, chal),
+train/parallel/evaluator.py:81-85)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _blobs(H, W, O, NB, C):
+    from alphazero_amd.network.model import fold_to_blob, random_net
+    return (fold_to_blob(random_net(H, W, O, NB, C, seed=1, perturb_bn=True)),
+            fold_to_blob(random_net(H, W, O, NB, C, seed=2, perturb_bn=True)))
+
+
+@pytest.mark.parametrize("H,C,dtype", [(5, 128, "fp32"), (9, 256, "bf16")])
+def test_two_network_routing_is_exact(H, C, dtype):
+    from alphazero_amd.engine import Engine
+    G, P, NB, O = 6, 10, 1, H * H + 1
+    max_turn = 12
+    kw = dict(n_slots=G, max_playout=P, transform_types=8, dirichlet_before=4, max_turn=max_turn, record_trajectories=True,
+              seed=11, num_blocks=NB, channels=C, tower_dtype=dtype)
+    blob_a, blob_b = _blobs(H, H, O, NB, C)
+    first = np.array([0, 1, 0, 1, 1, 0], np.int32)
+    rounds = (max_turn + 3) * (P + 1)
+
+    fast = Engine("go", H, H, **kw)
+    fast.tower_load(blob_a, net=0)
+    fast.tower_load(blob_b, net=1)
+    fast.selfplay_start()
+    fast.match_assign(np.arange(G), first)
+    fast.selfplay_run(rounds)
+
+    slow = Engine("go", H, H, **kw)
+    ta = Engine("go", H, H, n_slots=G, num_blocks=NB, channels=C, tower_dtype=dtype)
+    tb = Engine("go", H, H, n_slots=G, num_blocks=NB, channels=C, tower_dtype=dtype)
+    ta.tower_load(blob_a)
+    tb.tower_load(blob_b)
+    slow.selfplay_start()
+    for _ in range(rounds):
+        slow.selfplay_select()
+        planes, valid = slow.leaf_batch()
+        plies, _ = slow.selfplay_status()
+        pa, va = ta.tower_forward(planes)
+        pb, vb = tb.tower_forward(planes)
+        net = first ^ (plies & 1)              # side 0 (Black, player_1) searches on even plies
+        pri = np.where(net[:, None] == 0, pa, pb).astype(np.float32)
+        val = np.where(net == 0, va, vb).astype(np.float32)
+        slow.selfplay_finish(pri, val)
+
+    pf, df = fast.selfplay_status()
+    ps, ds = slow.selfplay_status()
+    assert np.array_equal(pf, ps) and np.array_equal(df, ds) and np.all(df == 1)
+    nets_differ = False
+    for s in range(G):
+        a, b = fast.trajectory_pop(s), slow.trajectory_pop(s)
+        assert np.array_equal(a["moves"], b["moves"]) and np.array_equal(a["visits"], b["visits"]) and a["winner"] == b["winner"]
+    # the two networks really are different (otherwise the routing would not be tested)
+    x = (np.random.RandomState(0).rand(2, 17, H, H) < 0.3).astype(np.int8)
+    nets_differ = np.abs(ta.tower_forward(x)[0] - tb.tower_forward(x)[0]).max() > 1e-4
+    assert nets_differ
+    for e in (fast, slow, ta, tb):
+        e.close()
+
+
+def test_batched_match_counts_like_the_reference():
+    import yaml
+    import os
+    from alphazero_amd.evaluator.nn_eval import NNEvaluator
+    from alphazero_amd.game.gameplay import BatchedMatch, gating_colors, gating_verdict
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "alphazero_amd", "config")
+    with open(os.path.join(root, "mnk.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    chal = NNEvaluator(cfg, num_blocks=1, channels=128, dtype="fp32", max_batch_size=2, seed=5)
+    best = NNEvaluator(cfg, num_blocks=1, channels=128, dtype="fp32", max_batch_size=2, seed=6)
+    ext = {"num_games": 7, "num_worker": 2,
+           "gameplay": {"dirichlet_before": 2, "log_iter": 30, "max_turn": 400, "player": {"max_playout": 8}}}
+    m = BatchedMatch(chal, best, cfg, ext, n_parallel=3, seed=3)
+    out = m.run(rounds_per_poll=16)
+    assert out["colors_of_new"] == gating_colors(7)
+    assert len(out["winners"]) == 7 and all(w in (-1, 0, 1) for w in out["winners"])
+    assert (out["win_counter"], out["num_not_tie"], out["accepted"]) == gating_verdict(out["winners"], out["colors_of_new"])
