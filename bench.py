@@ -91,7 +91,9 @@ def cpu_baseline(H, num_blocks, channels, sims, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    # default: a little more than one full 801-evaluation search per game, so that every game also goes through
+    # move choice, the real move and the re-root of both trees inside the timed region (about 12 s on one MI355X)
+    ap.add_argument("--steps", type=int, default=810)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--games", type=int, default=1024, help="concurrent games per GPU")
     ap.add_argument("--board", type=int, default=19)
@@ -178,7 +180,7 @@ def main():
                 "residual_blocks": args.blocks, "channels": args.channels, "parallelism": "games sharded, dp%d" % world,
                 "tower_gflop_per_eval": eng.tower_flops_per_eval() / 1e9,
             },
-            "moves_completed_in_timed_region": total_moves,
+            "moves_completed_in_timed_region": total_moves, "completed_moves_per_sec": total_moves / dt,
             "phase_ms_per_step": {"select": c["select_ms"] / args.steps, "tower": c["tower_ms"] / args.steps,
                                   "finish_move_reroot": c["finish_ms"] / args.steps},
             "tree_stats_per_sim": {"levels": c["levels"] / max(c["evals"], 1), "children_scanned": c["children_scanned"] / max(c["evals"], 1)},
