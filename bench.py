@@ -95,7 +95,8 @@ def main():
     # move choice, the real move and the re-root of both trees inside the timed region (about 12 s on one MI355X)
     ap.add_argument("--steps", type=int, default=810)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--games", type=int, default=1024, help="concurrent games per GPU")
+    ap.add_argument("--games", type=int, default=0,
+                    help="concurrent games per GPU; 0 = 4096, or fewer if the GPU's free memory does not hold their trees")
     ap.add_argument("--board", type=int, default=19)
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--blocks", type=int, default=20, help="residual blocks after the stem")
@@ -125,6 +126,12 @@ def main():
 
     H = args.board
     O = H * H + 1
+    if args.games <= 0:
+        # two tree arenas per game: 3*(sims+1)*O edges of 18 B and 8*(sims+1) blocks of 24 B each, plus state,
+        # trajectories and activations (about 0.7 MB); larger batches keep the tower's tiles flowing (fewer tails)
+        per_game = 2 * (3 * (args.sims + 1) * O * 18 + 8 * (args.sims + 1) * 24) + (402 * O * 4 + 402 * 2) + 3 * 441 * 256 * 2 + 64 * 1024
+        free, _ = torch.cuda.mem_get_info(local_rank)
+        args.games = int(max(256, min(4096, (int(0.85 * free) // per_game) // 256 * 256)))
     eng = Engine("go", H, H, n_slots=args.games, max_playout=args.sims, transform_types=8, dirichlet_before=30,
                  max_turn=400, d_alpha=0.03, d_epsilon=0.25, seed=1000 + rank, record_trajectories=True,
                  num_blocks=args.blocks, channels=args.channels, tower_dtype=args.dtype, device=local_rank)

@@ -133,5 +133,31 @@ int main(int argc, char **argv)
     ms /= iters;
     double fl = 2.0 * M * 9.0 * C * C;
     printf("variant %d resid %d B %d: %.4f ms  %.1f TFLOP/s  (%.1f%% of 2500)\n", variant, resid, B, ms, fl / ms / 1e9, fl / ms / 1e9 / 25.0);
+    if (getenv("TWO") && variant == 5 && B % 2 == 0) {
+        // the same work as two dependent chains of half-batch launches on two streams
+        hipStream_t s2[2];
+        CK(hipStreamCreate(&s2[0])); CK(hipStreamCreate(&s2[1]));
+        const int Mh = M / 2;
+        const size_t half = (size_t)(B / 2) * PP * C;
+        auto chain = [&](int n) {
+            for (int i = 0; i < n; i++)
+                for (int h = 0; h < 2; h++)
+                    launch_v5(X + h * half, Wt, bias, resid ? R + h * half : nullptr, Y + h * half, Mh, HW, Wd, PP, s2[h]);
+        };
+        chain(3);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, s2[0]));
+        CK(hipStreamWaitEvent(s2[1], e0, 0));
+        chain(iters);
+        hipEvent_t j;
+        CK(hipEventCreate(&j));
+        CK(hipEventRecord(j, s2[1]));
+        CK(hipStreamWaitEvent(s2[0], j, 0));
+        CK(hipEventRecord(e1, s2[0]));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= iters;
+        printf("two streams x half batch: %.4f ms per layer  %.1f TFLOP/s\n", ms, fl / ms / 1e9);
+    }
     return 0;
 }
