@@ -347,7 +347,7 @@ __device__ __forceinline__ void conv_epilogue(unsigned char *smem, const int *ro
 // every lane with 8 consecutive channels of one block (lane rows 0/2: block i, rows 1/3: block i+1), i.e.
 // one 16-byte piece of the NHWC row: bias, residual and ReLU are applied in fp32, rounded to bf16 once,
 // and stored.  Needs only `rowoff` from LDS, so no barrier is required before it.
-template <bool RESID>
+template <bool RESID, bool PRE = true>
 __device__ __forceinline__ void conv_epilogue_direct(const int *rowoff, f32x4 (&acc)[4][8], const float *__restrict__ bias,
                                                      const bf16_t *__restrict__ R, bf16_t *__restrict__ Y, int M, int m0, int lane_in,
                                                      int wr, int wc, const uint4 (&rpre)[8])
@@ -370,7 +370,7 @@ __device__ __forceinline__ void conv_epilogue_direct(const int *rowoff, f32x4 (&
             ok[j] = m0 + trow < M;
             off[j] = (long)rowoff[trow] * C + ch;
             if (RESID) {  // rows past M are clamped to a valid row in rowoff, so the load needs no predicate
-                if (ip == 0) rres[j] = rpre[j];
+                if (PRE && ip == 0) rres[j] = rpre[j];  // PRE: the caller fetched the first block pair's pieces earlier
                 else rres[j] = *reinterpret_cast<const uint4 *>(R + off[j]);
             }
         }
@@ -397,14 +397,10 @@ __device__ __forceinline__ void conv_epilogue_direct(const int *rowoff, f32x4 (&
 }
 
 // ---------------------------------------------------------------------------
-// Ping-pong variant of the kernel above.  Same tiles, LDS image, swizzle and epilogue; the
-// K loop is cut into half-steps (K = 32: 12 fragment reads, 32 MFMAs per wave) and the two
-// 4-wave groups (pixel halves wr = 0 / 1, which share the SIMDs pairwise) run one barrier
-// interval apart: while one group issues its MFMAs the other reads its next fragments from
-// LDS, so the matrix pipe of every SIMD always has a wave to serve.  LDS-DMA for K step k+1
-// is issued in interval 4k and retired (vmcnt 0) before the barrier that ends interval 4k+3.
+// Raw workgroup barrier for the ping-pong schedule of the slab kernel below (no implicit waitcnt, so
+// LDS-DMA stays in flight across it).  With -DSTAMP (development harness only) one workgroup records
+// the shader clock after every barrier.
 // ---------------------------------------------------------------------------
-#define HAVE_V3 1
 #ifdef STAMP
 __device__ unsigned long long g_stamps[2][512];
 #define PP_BAR() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); \
@@ -413,282 +409,17 @@ __device__ unsigned long long g_stamps[2][512];
 #define PP_BAR() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #endif
 
-template <bool RESID>
-__global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_pp(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
-                                                              const float *__restrict__ bias, const bf16_t *__restrict__ R,
-                                                              bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP)
-{
-    constexpr int C = 256;
-#ifdef STAMP
-    int stamp_i = 0;
-#endif
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[V2_LDS_BYTES];
-    int *rowoff = reinterpret_cast<int *>(smem + 147456);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
-    const int m0 = blockIdx.x * 256, W2 = Wd + 2;
-    if (tid < 256) {
-        int m = min(m0 + tid, M - 1);
-        int b = m / HW, pix = m - b * HW, y = pix / Wd, x = pix - y * Wd;
-        rowoff[tid] = b * PP + (y + 1) * W2 + (x + 1);
-    }
-    __syncthreads();
-    const int frow = lane >> 3, fslot = lane & 7;
-    int xoff[4], woff[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int r = wave * 32 + q * 8 + frow;
-        const int kc = fslot ^ ((r >> 1) & 7);
-        xoff[q] = rowoff[r] * C + kc * 8;
-        woff[q] = r * 9 * C + kc * 8;
-    }
-    unsigned char *const fill_base = smem + (wave * 32) * 128;
-    const int rd0 = (lane & 15) * 128 + ((((lane >> 4)) ^ ((lane & 15) >> 1)) << 4);
-    const int rd1 = (lane & 15) * 128 + ((((lane >> 4) + 4) ^ ((lane & 15) >> 1)) << 4);
-    const unsigned char *const wrd = smem + (wc * 64) * 128;
-    const unsigned char *const xrd = smem + 32768 + (wr * 128) * 128;
-
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 wf[4], xf[8];
-
-    auto issue = [&](int step) {
-#ifdef ABL_NODMA
-        if (step > 1) return;
-#endif
-        const int buf = step & 1;
-        // channel chunk outer, tap inner: the 9 taps re-read the same 128-byte lines back to back (L2 reuse)
-        const int cc = step / 9, tap = step - cc * 9, c0 = cc * 64;
-        const int ty = tap / 3, tx = tap - ty * 3;
-        const int toff = ((ty - 1) * W2 + (tx - 1)) * C + c0;
-        const int wofs = tap * C + c0;
-        unsigned char *dst = fill_base + buf * 65536;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            glds16(Wt + woff[q] + wofs, dst + q * 1024);
-            glds16(X + xoff[q] + toff, dst + 32768 + q * 1024);
-        }
-    };
-    auto rd_frags = [&](int h) {  // half-step h: K step h>>1, k32 half h&1
-        const int buf = (h >> 1) & 1;
-        const int rd = (h & 1) ? rd1 : rd0;
-        const unsigned char *wb = wrd + buf * 65536 + rd;
-        const unsigned char *xb = xrd + buf * 65536 + rd;
-#pragma unroll
-        for (int i = 0; i < 4; i++) wf[i] = *reinterpret_cast<const bf16x8 *>(wb + i * 2048);
-#pragma unroll
-        for (int j = 0; j < 8; j++) xf[j] = *reinterpret_cast<const bf16x8 *>(xb + j * 2048);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-    auto mfmas = [&]() {
-#ifdef ABL_NOMFMA
-        asm volatile("" :: "v"(wf[0]), "v"(xf[0]), "v"(wf[3]), "v"(xf[7]));
-        return;
-#endif
-#ifndef NO_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-#ifndef NO_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-    };
-
-    issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PP_BAR();
-    if (wr == 0) {
-        for (int k = 0; k < 36; k++) {
-            if (k + 1 < 36) issue(k + 1);
-            rd_frags(2 * k);
-            PP_BAR();
-            mfmas();
-            PP_BAR();
-            rd_frags(2 * k + 1);
-            PP_BAR();
-            mfmas();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PP_BAR();
-        }
-        PP_BAR();  // interval 144: the other group's last MFMAs
-    } else {
-        for (int k = 0; k < 36; k++) {
-            if (k + 1 < 36) issue(k + 1);
-            if (k > 0) mfmas();
-            PP_BAR();
-            rd_frags(2 * k);
-            PP_BAR();
-            mfmas();
-            PP_BAR();
-            rd_frags(2 * k + 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PP_BAR();
-        }
-        mfmas();
-        PP_BAR();
-    }
-    __syncthreads();
-    conv_epilogue<RESID>(smem, rowoff, acc, bias, R, Y, M, m0, wave, lane, wr, wc);
-}
-
-static inline void launch_v3(const bf16_t *X, const bf16_t *Wt, const float *bias, const bf16_t *R, bf16_t *Y, int M, int HW, int Wd,
-                             int PP, hipStream_t st = 0)
-{
-    dim3 g((M + 255) / 256), blk(512);
-    if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16_pp<true>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP);
-    else hipLaunchKernelGGL((k_conv3x3_c256_bf16_pp<false>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP);
-}
-
-// ---------------------------------------------------------------------------
-// Streaming ping-pong variant: K is cut into 72 half-steps of 32 input channels (one tap x 32
-// channels, channel chunk outer / tap inner).  LDS holds a ring of FOUR 32 KiB half-step buffers
-// (weights [256][64 B] + activations [256][64 B]); the LDS-DMA of half-step h+3 is issued while
-// half-step h is consumed and retired with a counted s_waitcnt vmcnt(8), so three half-steps
-// (96 KiB per CU) are always in flight.  Slot s of row r holds k-chunk s ^ ((4 - (r >> 2)) & 3).
-// The two 4-wave groups alternate LDS-read and MFMA intervals as in the variant above.
-// ---------------------------------------------------------------------------
-template <bool RESID>
-__global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_s4(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
-                                                              const float *__restrict__ bias, const bf16_t *__restrict__ R,
-                                                              bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP)
-{
-    constexpr int C = 256, NH = 72;
-#ifdef STAMP
-    int stamp_i = 0;
-#endif
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[V2_LDS_BYTES];
-    int *rowoff = reinterpret_cast<int *>(smem + 147456);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 2, wc = wave & 3;
-    const int m0 = blockIdx.x * 256, W2 = Wd + 2;
-    if (tid < 256) {
-        int m = min(m0 + tid, M - 1);
-        int b = m / HW, pix = m - b * HW, y = pix / Wd, x = pix - y * Wd;
-        rowoff[tid] = b * PP + (y + 1) * W2 + (x + 1);
-    }
-    __syncthreads();
-    // fill mapping: wave w fills rows w*32 + q*16 + (lane>>2), slot lane&3, of both half-tiles
-    const int frow = lane >> 2, fslot = lane & 3;
-    int xoff[2], woff[2];
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int r = wave * 32 + q * 16 + frow;
-        const int kc = fslot ^ ((4 - ((r >> 2) & 3)) & 3);
-        xoff[q] = rowoff[r] * C + kc * 8;
-        woff[q] = r * 9 * C + kc * 8;
-    }
-    unsigned char *const fill_base = smem + (wave * 32) * 64;
-    const int rdo = (lane & 15) * 64 + ((((lane >> 4)) ^ ((4 - ((lane & 15) >> 2)) & 3)) << 4);
-    const unsigned char *const wrd = smem + (wc * 64) * 64 + rdo;
-    const unsigned char *const xrd = smem + 16384 + (wr * 128) * 64 + rdo;
-
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 wf[4], xf[8];
-
-    auto issue = [&](int h) {
-#ifdef ABL_NODMA
-        if (h > 3) return;
-#endif
-        const int cc = h / 9, tap = h - cc * 9, c0 = cc * 32;
-        const int ty = tap / 3, tx = tap - ty * 3;
-        const int toff = ((ty - 1) * W2 + (tx - 1)) * C + c0;
-        const int wofs = tap * C + c0;
-        unsigned char *dst = fill_base + (h & 3) * 32768;
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            glds16(Wt + woff[q] + wofs, dst + q * 1024);
-            glds16(X + xoff[q] + toff, dst + 16384 + q * 1024);
-        }
-    };
-    auto rd_frags = [&](int h) {
-#ifdef ABL_NOREAD
-        if (h > 0) return;
-#endif
-        const unsigned char *wb = wrd + (h & 3) * 32768;
-        const unsigned char *xb = xrd + (h & 3) * 32768;
-#pragma unroll
-        for (int i = 0; i < 4; i++) wf[i] = *reinterpret_cast<const bf16x8 *>(wb + i * 1024);
-#pragma unroll
-        for (int j = 0; j < 8; j++) xf[j] = *reinterpret_cast<const bf16x8 *>(xb + j * 1024);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-    auto mfmas = [&]() {
-#ifdef ABL_NOMFMA
-        asm volatile("" :: "v"(wf[0]), "v"(xf[0]), "v"(wf[3]), "v"(xf[7]));
-        return;
-#endif
-#ifndef NO_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-#ifndef NO_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-    };
-    auto retire = [&](int h) {  // half-step h+1 must have landed; up to two younger ones stay in flight
-        if (h <= NH - 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (h == NH - 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-
-    issue(0); issue(1); issue(2);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    PP_BAR();
-    if (wr == 0) {
-        for (int h = 0; h < NH; h++) {
-            if (h + 3 < NH) issue(h + 3);
-            rd_frags(h);
-            PP_BAR();
-            mfmas();
-            retire(h);
-            PP_BAR();
-        }
-        PP_BAR();
-    } else {
-        for (int h = 0; h < NH; h++) {
-            if (h + 3 < NH) issue(h + 3);
-            if (h > 0) mfmas();
-            PP_BAR();
-            rd_frags(h);
-            retire(h);
-            PP_BAR();
-        }
-        mfmas();
-        PP_BAR();
-    }
-    __syncthreads();
-    conv_epilogue<RESID>(smem, rowoff, acc, bias, R, Y, M, m0, wave, lane, wr, wc);
-}
-
-static inline void launch_v4(const bf16_t *X, const bf16_t *Wt, const float *bias, const bf16_t *R, bf16_t *Y, int M, int HW, int Wd,
-                             int PP, hipStream_t st = 0)
-{
-    dim3 g((M + 255) / 256), blk(512);
-    if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16_s4<true>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP);
-    else hipLaunchKernelGGL((k_conv3x3_c256_bf16_s4<false>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP);
-}
-
 // ---------------------------------------------------------------------------
 // Slab variant (the one the tower uses when the tile's pixel span fits): the activation operand
 // is NOT re-fetched per tap.  For each 32-channel chunk the workgroup loads once, by LDS-DMA, the
 // "slab" of all padded positions its 256 pixels touch through any of the 9 taps (a contiguous range
 // of at most NSP*128 padded positions, 64 B each) and the 9 taps read it at shifted rows; only the
-// weight half-tiles stream per half-step (ring of 4 x 16 KiB, three in flight).  L2->LDS traffic per
+// weight half-tiles stream per half-step (ring of 4 x 16 KiB, three in flight).  The K loop is cut into
+// half-steps (one tap x 32 channels: 12 fragment reads, 32 MFMAs per wave) and the two 4-wave groups
+// (pixel halves wr = 0 / 1, which share the SIMDs pairwise) run one barrier interval apart: while one
+// group issues its MFMAs (and its share of the LDS-DMA) the other reads its next fragments from LDS, so
+// the matrix pipe of every SIMD always has a wave to serve.  DMA completion is tracked with counted
+// s_waitcnt vmcnt(N), never 0 inside the loop.  L2->LDS traffic per
 // tile drops from 2.36 MB to 1.37 MB.  Slot s of a 64-byte row r holds k-chunk s ^ (((r >> 2) & 1) << 1),
 // which keeps ds_read_b128 conflict-free for any alignment of 16 consecutive rows.
 // ---------------------------------------------------------------------------

@@ -62,17 +62,9 @@ int main(int argc, char **argv)
             if (resid) hipLaunchKernelGGL((k_conv3x3_c256_bf16<true>), g, blk, 0, 0, X, Wt, bias, R, Y, M, HW, Wd, PP);
             else hipLaunchKernelGGL((k_conv3x3_c256_bf16<false>), g, blk, 0, 0, X, Wt, bias, (const bf16_t *)nullptr, Y, M, HW, Wd, PP);
             break;
-#ifdef HAVE_V3
-        case 3:
-            launch_v3(X, Wt, bias, resid ? R : nullptr, Y, M, HW, Wd, PP);
-            break;
-        case 4:
-            launch_v4(X, Wt, bias, resid ? R : nullptr, Y, M, HW, Wd, PP);
-            break;
         case 5:
             if (!launch_v5(X, Wt, bias, resid ? R : nullptr, Y, M, HW, Wd, PP)) { printf("slab kernel not applicable\n"); exit(1); }
             break;
-#endif
         }
     };
     launch();
