@@ -38,7 +38,7 @@ def measured_traffic(games, board, channels):
     return d["traffic_bytes_per_launch"], d["source"]
 
 
-def cpu_baseline(H, num_blocks, channels, sims, budget_s=20.0):
+def cpu_baseline(game, H, k, num_blocks, channels, sims, budget_s=20.0):
     """The CPU oracle (C port of the reference's rules/search) driving an fp32 PyTorch-CPU restatement of
     the network, one leaf per evaluation as the reference's per-game search sees it; bounded sample."""
     import numpy as np
@@ -47,7 +47,7 @@ def cpu_baseline(H, num_blocks, channels, sims, budget_s=20.0):
     from oracle import oracle as oz
     from oracle import tower_ref
 
-    O = H * H + 1
+    O = H * H + (0 if game == "mnk" else 1)
     net = random_net(H, H, O, num_blocks, channels, seed=0)
     sd = net.state_dict()
     cores = torch.get_num_threads()
@@ -60,7 +60,7 @@ def cpu_baseline(H, num_blocks, channels, sims, budget_s=20.0):
         return p[0].numpy(), float(v[0])
 
     cb = oz.make_eval(ev)
-    st = oz.State("go", H, H)
+    st = oz.State(game, H, H, k) if game == "mnk" else oz.State(game, H, H)
     tree = oz.Tree(O, 8)
     rng = oz.Rng(seed=1)
     # calibrate with a few playouts, then size the sample to the budget
@@ -83,8 +83,8 @@ def cpu_baseline(H, num_blocks, channels, sims, budget_s=20.0):
     return {
         "reference_python_in_build_container": ref,
         "value": sims_per_s / (sims + 1), "unit": "moves/s", "sims_per_sec": sims_per_s, "cores": cores, "kind": "port",
-        "sample": "first %d simulations of one Go %dx%d game's first search (%d-block %d-ch fp32 net on CPU, "
-                  "one leaf per evaluation); moves/s = sims/s / %d" % (n_eval[0], H, H, num_blocks, channels, sims + 1),
+        "sample": "first %d simulations of one %s %dx%d game's first search (%d-block %d-ch fp32 net on CPU, "
+                  "one leaf per evaluation); moves/s = sims/s / %d" % (n_eval[0], game, H, H, num_blocks, channels, sims + 1),
     }
 
 
@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--games", type=int, default=0,
                     help="concurrent games per GPU; 0 = 4096, or fewer if the GPU's free memory does not hold their trees")
+    ap.add_argument("--game", default="go", choices=["go", "reversi", "mnk"],
+                    help="rule set; the headline workload is go (the other games are the smaller configurations)")
+    ap.add_argument("--k", type=int, default=5, help="stones in a row for mnk")
     ap.add_argument("--board", type=int, default=19)
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--blocks", type=int, default=20, help="residual blocks after the stem")
@@ -125,14 +128,14 @@ def main():
     from alphazero_amd import parallel
 
     H = args.board
-    O = H * H + 1
+    O = H * H + (0 if args.game == "mnk" else 1)
     if args.games <= 0:
         # two tree arenas per game: 3*(sims+1)*O edges of 18 B and 8*(sims+1) blocks of 24 B each, plus state,
         # trajectories and activations (about 0.7 MB); larger batches keep the tower's tiles flowing (fewer tails)
         per_game = 2 * (3 * (args.sims + 1) * O * 18 + 8 * (args.sims + 1) * 24) + (402 * O * 4 + 402 * 2) + 3 * 441 * 256 * 2 + 64 * 1024
         free, _ = torch.cuda.mem_get_info(local_rank)
         args.games = int(max(256, min(4096, (int(0.85 * free) // per_game) // 256 * 256)))
-    eng = Engine("go", H, H, n_slots=args.games, max_playout=args.sims, transform_types=8, dirichlet_before=30,
+    eng = Engine(args.game, H, H, args.k, n_slots=args.games, max_playout=args.sims, transform_types=8, dirichlet_before=30,
                  max_turn=400, d_alpha=0.03, d_epsilon=0.25, seed=1000 + rank, record_trajectories=True,
                  num_blocks=args.blocks, channels=args.channels, tower_dtype=args.dtype, device=local_rank)
     # weights: rank 0 builds them, every rank receives them over RCCL (model update path)
@@ -180,9 +183,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {
-                "workload": "Go %dx%d self-play, %d sims/move, stem + %d residual blocks x %d ch dual-head ResNet, "
+                "workload": "%s %dx%d self-play, %d sims/move, stem + %d residual blocks x %d ch dual-head ResNet, "
                             "%d concurrent games per GPU, dihedral transforms on, Dirichlet noise on the first 31 plies"
-                            % (H, H, args.sims, args.blocks, args.channels, args.games),
+                            % ({"go": "Go", "reversi": "Reversi", "mnk": "m,n,k (k=%d)" % args.k}[args.game], H, H, args.sims,
+                               args.blocks, args.channels, args.games),
                 "games_per_gpu": args.games, "sims_per_move": args.sims, "evals_per_move_used": evals_per_move,
                 "residual_blocks": args.blocks, "channels": args.channels, "parallelism": "games sharded, dp%d" % world,
                 "tower_gflop_per_eval": eng.tower_flops_per_eval() / 1e9,
@@ -200,7 +204,7 @@ def main():
             "tower_tflops_end_to_end": (c["tower_evals"] * eng.tower_flops_per_eval()) / (c["tower_ms"] * 1e-3) / 1e12 if c["tower_ms"] > 0 else 0.0,
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only; at N>1 the other ranks would idle behind it
-            out["cpu_baseline"] = cpu_baseline(H, args.blocks, args.channels, args.sims)
+            out["cpu_baseline"] = cpu_baseline(args.game, H, args.k, args.blocks, args.channels, args.sims)
         print(json.dumps(out))
     eng.close()
     if dist is not None:
