@@ -88,6 +88,21 @@ def cpu_baseline(game, H, k, num_blocks, channels, sims, budget_s=20.0):
     }
 
 
+def hbm_kernels(c, cells, O, steps, peak_gbs=8000.0):
+    """Achieved GB/s of the search-side phases against the HBM peak.  Algorithmic bytes: per simulation the 3 KiB
+    state ring read, 12 B per child scanned (N, W, P) + 8 B per level, 17 int8 planes + the legal mask written
+    (select); the priors row and mask read, 18 B per edge created, 8 B per level backed up (finish)."""
+    ev = max(c["evals"], 1)
+    sel_bytes = ev * (8 * 384 + 17 * cells + O) + 12 * c["children_scanned"] + 8 * c["levels"]
+    fin_bytes = ev * (4 * O + O) + 18 * c["edges_created"] + 8 * c["levels"]
+    out = []
+    for name, nbytes, ms in (("k_select", sel_bytes, c["select_ms"]), ("k_finish+k_move+k_reroot", fin_bytes, c["finish_ms"])):
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out.append({"kernel": name, "bound": "hbm", "achieved": gbs, "peak": peak_gbs, "unit": "GB/s", "frac": gbs / peak_gbs,
+                    "bytes_per_sim": nbytes / ev, "ms_per_step": ms / steps})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,6 +216,8 @@ def main():
                 "frac": achieved / MFMA_PEAK_TFLOPS_BF16, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": conv_ms, "launches": c["conv_launches"], "flops_per_launch": c["conv_flops_per_launch"],
             },
+            # HBM-side kernels: algorithmic bytes from the engine's counters / kernel time (HIP events around each phase)
+            "hbm_kernels": hbm_kernels(c, H * H, O, args.steps),
             "tower_tflops_end_to_end": (c["tower_evals"] * eng.tower_flops_per_eval()) / (c["tower_ms"] * 1e-3) / 1e12 if c["tower_ms"] > 0 else 0.0,
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only; at N>1 the other ranks would idle behind it

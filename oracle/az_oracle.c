@@ -479,8 +479,8 @@ static double rng_uni(OzRng *r)
 typedef struct {
     int parent;
     int n;          /* _visit_cnt */
-    float w;        /* _total_action_val */
-    float p;        /* _prior_prob */
+    oz_real w;        /* _total_action_val */
+    oz_real p;        /* _prior_prob */
     int first, cnt; /* children, contiguous, insertion order */
     int action;
 } OzNode;
@@ -493,7 +493,7 @@ struct OzTree {
     double d_alpha, d_epsilon;
 };
 
-static const float C_PUNT = 5.0f; /* mcts.py:9 */
+static const oz_real C_PUNT = (oz_real)5.0; /* mcts.py:9 */
 
 static int tree_alloc(OzTree *t, int n)
 {
@@ -531,13 +531,13 @@ void oz_tree_free(OzTree *t) { if (t) { free(t->nodes); free(t); } }
 int64_t oz_tree_num_nodes(const OzTree *t) { return t->used; }
 
 /* mcts.py:80-103, evaluated left to right in float32 */
-static float sel_value(const OzTree *t, const OzNode *c)
+static oz_real sel_value(const OzTree *t, const OzNode *c)
 {
     const OzNode *par = &t->nodes[c->parent];
-    float u = C_PUNT * c->p;
-    u = u * (float)sqrt((double)par->n);
-    u = u / (float)(1.0 + (double)c->n);
-    float q = c->n == 0 ? 0.0f : c->w / (float)c->n;
+    oz_real u = C_PUNT * c->p;
+    u = u * (oz_real)sqrt((double)par->n);
+    u = u / (oz_real)(1.0 + (double)c->n);
+    oz_real q = c->n == 0 ? (oz_real)0.0 : c->w / (oz_real)c->n;
     return q + u;
 }
 
@@ -546,9 +546,9 @@ static int tree_select(const OzTree *t, int node)
 {
     const OzNode *nd = &t->nodes[node];
     int best = nd->first;
-    float bv = sel_value(t, &t->nodes[best]);
+    oz_real bv = sel_value(t, &t->nodes[best]);
     for (int i = 1; i < nd->cnt; i++) {
-        float v = sel_value(t, &t->nodes[nd->first + i]);
+        oz_real v = sel_value(t, &t->nodes[nd->first + i]);
         if (v > bv) { bv = v; best = nd->first + i; }
     }
     return best;
@@ -558,10 +558,10 @@ static int tree_select(const OzTree *t, int node)
  * draw a transform id, evaluate the transformed copy, relabel, keep legal
  * entries in list order.  Returns the candidate count. */
 static int eval_candidates(OzTree *t, const OzState *s, oz_eval_fn ev, void *ctx, OzRng *rng,
-                           int *acts, float *probs, float *value)
+                           int *acts, oz_real *probs, oz_real *value)
 {
     int8_t planes[OZ_NPLANES * OZ_MAXC];
-    float pri[OZ_MAXO];
+    oz_real pri[OZ_MAXO];
     int tid = 0, n = 0;
     int enable = !(t->transform_types == 0 || t->transform_types == 1);
     if (enable) tid = rng_tid(rng, t->transform_types);
@@ -575,7 +575,7 @@ static int eval_candidates(OzTree *t, const OzState *s, oz_eval_fn ev, void *ctx
 }
 
 /* mcts.py:30-52 */
-static void tree_expand(OzTree *t, int node, const int *acts, const float *probs, int n, float value)
+static void tree_expand(OzTree *t, int node, const int *acts, const oz_real *probs, int n, oz_real value)
 {
     if (t->nodes[node].cnt != 0) return;
     t->nodes[node].w += value;
@@ -590,25 +590,25 @@ static void tree_expand(OzTree *t, int node, const int *acts, const float *probs
 }
 
 /* mcts.py:173-232 */
-static float tree_playout(OzTree *t, OzState *s, int node, oz_eval_fn ev, void *ctx, OzRng *rng)
+static oz_real tree_playout(OzTree *t, OzState *s, int node, oz_eval_fn ev, void *ctx, OzRng *rng)
 {
     t->nodes[node].n++;
     if (t->nodes[node].cnt != 0) {
         int c = tree_select(t, node);
         int player = s->cur;
         oz_do_move(s, t->nodes[c].action);
-        float v = tree_playout(t, s, c, ev, ctx, rng);
-        t->nodes[node].w += (float)(-player) * v;
+        oz_real v = tree_playout(t, s, c, ev, ctx, rng);
+        t->nodes[node].w += (oz_real)(-player) * v;
         return v;
     }
     int acts[OZ_MAXO];
-    float probs[OZ_MAXO], value;
+    oz_real probs[OZ_MAXO], value;
     int n = eval_candidates(t, s, ev, ctx, rng, acts, probs, &value);
     if (n != 0 && !s->is_end) {
-        tree_expand(t, node, acts, probs, n, (float)(-s->cur) * value);
+        tree_expand(t, node, acts, probs, n, (oz_real)(-s->cur) * value);
     } else {
-        value = (float)oz_winner(s);
-        t->nodes[node].w += (float)(-s->cur) * value;
+        value = (oz_real)oz_winner(s);
+        t->nodes[node].w += (oz_real)(-s->cur) * value;
     }
     return value;
 }
@@ -628,7 +628,7 @@ int oz_tree_search(OzTree *t, const OzState *s, int max_playout, int dirichlet,
     t->nodes[t->root].n++;
     if (t->nodes[t->root].cnt == 0) {
         int acts[OZ_MAXO];
-        float probs[OZ_MAXO], value;
+        oz_real probs[OZ_MAXO], value;
         int n = eval_candidates(t, s, ev, ctx, rng, acts, probs, &value);
         tree_expand(t, t->root, acts, probs, n, value); /* raw value: mcts.py:283 */
         evals++;
@@ -636,12 +636,12 @@ int oz_tree_search(OzTree *t, const OzState *s, int max_playout, int dirichlet,
     if (dirichlet) {
         /* mcts.py:285-291; math_helper.py:13-17 (un-normalised gamma draws) */
         OzNode *r = &t->nodes[t->root];
-        float keep = (float)(1.0 - t->d_epsilon);
+        oz_real keep = (oz_real)(1.0 - t->d_epsilon);
         for (int i = 0; i < r->cnt; i++) {
             double eta = rng_eta(rng, t->d_alpha);
             OzNode *c = &t->nodes[r->first + i];
-            float a = keep * c->p;
-            c->p = a + (float)(t->d_epsilon * eta);
+            oz_real a = keep * c->p;
+            c->p = a + (oz_real)(t->d_epsilon * eta);
         }
     }
     for (int i = 0; i < max_playout; i++) {
@@ -653,7 +653,7 @@ int oz_tree_search(OzTree *t, const OzState *s, int max_playout, int dirichlet,
     return evals;
 }
 
-int oz_tree_root_stats(const OzTree *t, int32_t *actions, int32_t *visits, float *W, float *P)
+int oz_tree_root_stats(const OzTree *t, int32_t *actions, int32_t *visits, oz_real *W, oz_real *P)
 {
     const OzNode *r = &t->nodes[t->root];
     for (int i = 0; i < r->cnt; i++) {
@@ -793,7 +793,7 @@ static inline uint64_t mix64(uint64_t z)
 
 /* Same arithmetic as oracle/fake_eval.py (numpy): a position hash drives
  * float32 priors in (0, 4/O] and a float32 value in [-0.5, 0.5). */
-void oz_fake_eval(void *ctx, const int8_t *planes, int H, int W, int O, float *priors, float *value)
+void oz_fake_eval(void *ctx, const int8_t *planes, int H, int W, int O, oz_real *priors, oz_real *value)
 {
     (void)ctx;
     uint64_t h = 0;
@@ -812,10 +812,10 @@ void oz_fake_eval(void *ctx, const int8_t *planes, int H, int W, int O, float *p
     *value = (float)((double)(z >> 40) - 8388608.0) * (1.0f / 16777216.0f);
 }
 
-void oz_uniform_eval(void *ctx, const int8_t *planes, int H, int W, int O, float *priors, float *value)
+void oz_uniform_eval(void *ctx, const int8_t *planes, int H, int W, int O, oz_real *priors, oz_real *value)
 {
     (void)ctx; (void)planes; (void)H; (void)W;
-    float p = (float)(1.0 / (double)O);
+    oz_real p = (oz_real)(1.0 / (double)O);  /* np.full((dims,), 1 / dims) in the evaluator's dtype */
     for (int i = 0; i < O; i++) priors[i] = p;
-    *value = 0.0f;
+    *value = (oz_real)0.0;
 }

@@ -19,6 +19,15 @@
 #define AZ_ORACLE_H
 #include <stdint.h>
 
+/* Arithmetic type of the search statistics W, P and of the evaluator's outputs.  float reproduces the
+ * reference with a float32 evaluator (the neural network); building with -DOZ_REAL=double reproduces it
+ * with an evaluator that returns Python floats / float64 (evaluator/dummy_eval.py:26-28), where NumPy and
+ * Python keep every intermediate in double. */
+#ifndef OZ_REAL
+#define OZ_REAL float
+#endif
+typedef OZ_REAL oz_real;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -68,7 +77,7 @@ int oz_reverse_label(int idx, int H, int W, int tid);
 
 /* ---- search ---- */
 typedef void (*oz_eval_fn)(void *ctx, const int8_t *planes, int H, int W, int O,
-                           float *priors, float *value);
+                           oz_real *priors, oz_real *value);
 
 typedef struct {
     const int32_t *tids; int64_t n_tids, i_tids;       /* transform ids */
@@ -86,7 +95,7 @@ int oz_tree_search(OzTree *t, const OzState *s, int max_playout, int dirichlet,
                    oz_eval_fn ev, void *ctx, OzRng *rng);
 /* root children in insertion order */
 int oz_tree_root_stats(const OzTree *t, int32_t *actions, int32_t *visits,
-                       float *W, float *P);
+                       oz_real *W, oz_real *P);
 int oz_tree_root_visits(const OzTree *t);
 int oz_tree_choose(const OzTree *t, double u);          /* weighted_random_choice */
 int oz_tree_argmax(const OzTree *t);                    /* calc_move(prop_exp=False) */
@@ -117,10 +126,10 @@ int oz_play_game(const OzGameCfg *cfg, oz_eval_fn ev, void *ctx, OzRng *rng,
 
 /* deterministic hash evaluator shared with the fixture generator */
 void oz_fake_eval(void *ctx, const int8_t *planes, int H, int W, int O,
-                  float *priors, float *value);
+                  oz_real *priors, oz_real *value);
 /* uniform priors 1/O (float32), value 0 */
 void oz_uniform_eval(void *ctx, const int8_t *planes, int H, int W, int O,
-                     float *priors, float *value);
+                     oz_real *priors, oz_real *value);
 
 uint64_t oz_splitmix64(uint64_t *x);
 double oz_gamma_small_alpha(double alpha, uint64_t *st);

@@ -183,17 +183,23 @@ class FakeEvaluator:
     """eval(state) -> ([(action, np.float32)], np.float32): the evaluator contract of
     evaluator/nn_eval_parallel.py:75-92 with the network replaced by a hash."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, real64=None):
         self.cfg = cfg
         self.conv = sc.StateTensorConverter(cfg)
         self.t2a = sc.TensorActionConverter(cfg)
         self.calls = 0
+        self.real64 = real64  # None: float32 outputs; "fake": the same hash widened to float64; "uniform": DummyEvaluator
 
     def eval(self, state):
         self.calls += 1
         planes = self.conv.state_to_tensor(state)[0]
+        if self.real64 == "uniform":  # evaluator/dummy_eval.py:26-28: np.full float64 priors, Python int 0
+            dims = self.cfg["flat_move_output"]
+            return self.t2a.tensor_to_action(np.full((dims,), 1 / dims)), 0
         pri, v = fake_eval_planes(planes, self.cfg["flat_move_output"])
         assert pri.dtype == np.float32 and isinstance(v, np.float32)
+        if self.real64 == "fake":
+            return self.t2a.tensor_to_action(pri.astype(np.float64)), float(v)
         return self.t2a.tensor_to_action(pri), v
 
 
@@ -230,30 +236,35 @@ def install_rng_hooks(streams):
     mcts.weighted_random_choice = _wrc
 
 
-def root_record(search, H, W, O):
+def root_record(search, H, W, O, real64=False):
     ch = search._root.children
     acts = np.full(O, -1, np.int32)
     N = np.zeros(O, np.int32)
-    Wv = np.zeros(O, np.float32)
-    P = np.zeros(O, np.float32)
+    rt = np.float64 if real64 else np.float32
+    Wv = np.zeros(O, rt)
+    P = np.zeros(O, rt)
     for i, (a, nd) in enumerate(ch.items()):
         acts[i] = a2i(a, H, W)
         N[i] = nd._visit_cnt
         w = nd._total_action_val
-        assert isinstance(w, (np.float32, int)), type(w)
-        assert isinstance(nd._prior_prob, np.float32), type(nd._prior_prob)
-        Wv[i] = np.float32(w)
+        if real64:
+            assert isinstance(w, (float, np.float64, int)), type(w)
+            assert isinstance(nd._prior_prob, (float, np.float64)), type(nd._prior_prob)
+        else:
+            assert isinstance(w, (np.float32, int)), type(w)
+            assert isinstance(nd._prior_prob, np.float32), type(nd._prior_prob)
+        Wv[i] = rt(w)
         P[i] = nd._prior_prob
     return len(ch), acts, N, Wv, P, search._root._visit_cnt
 
 
 def search_trace(name, game, H, W, k, transform_types, max_playout, dirichlet_before, max_turn,
-                 seed, ply_limit, use_game_class=False):
+                 seed, ply_limit, use_game_class=False, real64=None):
     cfg = cfg_for(game, H, W, transform_types, k)
     O = cfg["flat_move_output"]
     streams = Streams(seed)
     install_rng_hooks(streams)
-    ev = FakeEvaluator(cfg)
+    ev = FakeEvaluator(cfg, real64)
     ext = {"player": {"max_playout": max_playout}, "dirichlet_before": dirichlet_before,
            "log_iter": 10 ** 9, "max_turn": max_turn}
     recs = []
@@ -263,7 +274,7 @@ def search_trace(name, game, H, W, k, transform_types, max_playout, dirichlet_be
     def think_hook(orig):
         def _think(self, state, dirichlet=False):
             move, probs = orig(self, state, dirichlet)
-            n, acts, N, Wv, P, rootN = root_record(self.mcts, H, W, O)
+            n, acts, N, Wv, P, rootN = root_record(self.mcts, H, W, O, real64 is not None)
             recs.append(dict(n=n, acts=acts, N=N, W=Wv, P=P, rootN=rootN, move=a2i(move, H, W),
                              dirichlet=int(bool(dirichlet)), n_tids=len(streams.tids),
                              n_etas=len(streams.etas), n_unis=len(streams.unis),
@@ -306,8 +317,9 @@ def search_trace(name, game, H, W, k, transform_types, max_playout, dirichlet_be
         n_children=np.array([r["n"] for r in recs], np.int32),
         acts=np.array([r["acts"] for r in recs], np.int32),
         N=np.array([r["N"] for r in recs], np.int32),
-        Wv=np.array([r["W"] for r in recs], np.float32),
-        P=np.array([r["P"] for r in recs], np.float32),
+        Wv=np.array([r["W"] for r in recs], np.float64 if real64 else np.float32),
+        P=np.array([r["P"] for r in recs], np.float64 if real64 else np.float32),
+        evaluator=real64 or "fake32",
         rootN=np.array([r["rootN"] for r in recs], np.int32),
         moves=np.array([r["move"] for r in recs], np.int32),
         dirichlet=np.array([r["dirichlet"] for r in recs], np.int8),
@@ -334,7 +346,18 @@ def save(name, d):
     print("%-28s %8.1f KB" % (name, os.path.getsize(path) / 1024.0))
 
 
+def main64():
+    """Float64 evaluators (DummyEvaluator's uniform priors / the hash widened to double): every search
+    intermediate is then a Python float or np.float64 in the reference."""
+    save("search64_go9_uniform", search_trace("go9u", "go", 9, 9, None, 8, 120, 30, 400, 31, 8, real64="uniform"))
+    save("search64_go5_fake", search_trace("go5f", "go", 5, 5, None, 8, 60, 4, 60, 32, 40, real64="fake"))
+    save("search64_reversi_fake", search_trace("rev", "reversi", 8, 8, None, 8, 32, 30, 400, 33, 24, real64="fake"))
+    save("search64_ttt_uniform", search_trace("tttu", "mnk", 3, 3, 3, 0, 100, 30, 400, 34, 10 ** 9, real64="uniform"))
+
+
 def main():
+    if "--only64" in sys.argv:
+        return main64()
     # ---- transforms: label tables of ReverseTransformer and forward board maps
     tabs = {}
     for n in (3, 5, 7, 8, 9, 19):
@@ -404,6 +427,7 @@ def main():
     save("search_go5_game", search_trace("go5", "go", 5, 5, None, 8, 60, 4, 60, 25, 80))
     save("search_go9", search_trace("go9", "go", 9, 9, None, 8, 64, 30, 400, 26, 20))
     save("search_go19", search_trace("go19", "go", 19, 19, None, 8, 30, 30, 400, 27, 6))
+    main64()
     mnk.game_config.update(board_height=6, board_width=5, k=4)
 
 

@@ -12,6 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle.so")
+_SO64 = os.path.join(_HERE, "liboracle64.so")   # same source built with -DOZ_REAL=double
 
 GO, REVERSI, MNK = 0, 1, 2
 GAME_IDS = {"go": GO, "reversi": REVERSI, "mnk": MNK}
@@ -66,16 +67,19 @@ class OzTrajectory(C.Structure):
 
 EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int8), C.c_int, C.c_int, C.c_int,
                       C.POINTER(C.c_float), C.POINTER(C.c_float))
+EVAL_FN64 = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int8), C.c_int, C.c_int, C.c_int,
+                        C.POINTER(C.c_double), C.POINTER(C.c_double))
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_SO):
+def lib(real64=False):
+    """The oracle library; real64 selects the build whose search statistics are float64."""
+    if real64 not in _libs:
+        so = _SO64 if real64 else _SO
+        if not os.path.exists(so):
             build()
-        L = C.CDLL(_SO)
+        L = C.CDLL(so)
         SP = C.POINTER(OzState)
         L.oz_init.argtypes = [SP, C.c_int, C.c_int, C.c_int, C.c_int]
         L.oz_copy.argtypes = [SP, SP]
@@ -104,12 +108,12 @@ def lib():
                                    C.POINTER(OzTrajectory), C.c_int]
         L.oz_gamma_small_alpha.restype = C.c_double
         L.oz_gamma_small_alpha.argtypes = [C.c_double, C.POINTER(C.c_uint64)]
-        _lib = L
-    return _lib
+        _libs[real64] = L
+    return _libs[real64]
 
 
-def fn_ptr(name):
-    return C.cast(getattr(lib(), name), C.c_void_p)
+def fn_ptr(name, real64=False):
+    return C.cast(getattr(lib(real64), name), C.c_void_p)
 
 
 class State:
@@ -183,49 +187,54 @@ class Rng:
         self.r.seed = seed
 
 
-def make_eval(pyfunc):
-    """pyfunc(planes int8 (17,H,W), O) -> (priors float32[O], value float) -> C callback."""
+def make_eval(pyfunc, real64=False):
+    """pyfunc(planes int8 (17,H,W), O) -> (priors[O], value) -> C callback in the library's real type."""
+    rt = np.float64 if real64 else np.float32
+
     def _cb(ctx, planes, H, W, O, priors, value):
         p = np.ctypeslib.as_array(planes, shape=(NPLANES, H, W))
         pr, v = pyfunc(p, O)
-        np.ctypeslib.as_array(priors, shape=(O,))[:] = np.asarray(pr, dtype=np.float32)
-        value[0] = np.float32(v)
-    return EVAL_FN(_cb)
+        np.ctypeslib.as_array(priors, shape=(O,))[:] = np.asarray(pr, dtype=rt)
+        value[0] = rt(v)
+    return (EVAL_FN64 if real64 else EVAL_FN)(_cb)
 
 
 class Tree:
-    def __init__(self, O, transform_types, d_alpha=0.03, d_epsilon=0.25):
+    def __init__(self, O, transform_types, d_alpha=0.03, d_epsilon=0.25, real64=False):
         self.O = O
-        self.t = lib().oz_tree_new(O, transform_types, d_alpha, d_epsilon)
+        self.real64 = real64
+        self.L = lib(real64)
+        self.t = self.L.oz_tree_new(O, transform_types, d_alpha, d_epsilon)
 
     def __del__(self):
         if getattr(self, "t", None):
-            lib().oz_tree_free(self.t)
+            self.L.oz_tree_free(self.t)
             self.t = None
 
     def search(self, state, max_playout, dirichlet, ev, rng):
         evp = ev if isinstance(ev, C.c_void_p) else C.cast(ev, C.c_void_p)
-        return lib().oz_tree_search(self.t, C.byref(state.s), max_playout, int(dirichlet), evp, None, C.byref(rng.r))
+        return self.L.oz_tree_search(self.t, C.byref(state.s), max_playout, int(dirichlet), evp, None, C.byref(rng.r))
 
     def playout(self, state, ev, rng):
         evp = ev if isinstance(ev, C.c_void_p) else C.cast(ev, C.c_void_p)
-        lib().oz_tree_playout(self.t, C.byref(state.s), evp, None, C.byref(rng.r))
+        self.L.oz_tree_playout(self.t, C.byref(state.s), evp, None, C.byref(rng.r))
 
     def root_stats(self):
         a = np.zeros(self.O, np.int32); n = np.zeros(self.O, np.int32)
-        w = np.zeros(self.O, np.float32); p = np.zeros(self.O, np.float32)
-        c = lib().oz_tree_root_stats(self.t, a.ctypes.data, n.ctypes.data, w.ctypes.data, p.ctypes.data)
+        rt = np.float64 if self.real64 else np.float32
+        w = np.zeros(self.O, rt); p = np.zeros(self.O, rt)
+        c = self.L.oz_tree_root_stats(self.t, a.ctypes.data, n.ctypes.data, w.ctypes.data, p.ctypes.data)
         return a[:c], n[:c], w[:c], p[:c]
 
-    def root_visits(self): return lib().oz_tree_root_visits(self.t)
-    def choose(self, u): return lib().oz_tree_choose(self.t, float(u))
-    def argmax(self): return lib().oz_tree_argmax(self.t)
-    def update_with_move(self, a): lib().oz_tree_update_with_move(self.t, int(a))
-    def count_expanded(self): return lib().oz_tree_count_expanded(self.t)
+    def root_visits(self): return self.L.oz_tree_root_visits(self.t)
+    def choose(self, u): return self.L.oz_tree_choose(self.t, float(u))
+    def argmax(self): return self.L.oz_tree_argmax(self.t)
+    def update_with_move(self, a): self.L.oz_tree_update_with_move(self.t, int(a))
+    def count_expanded(self): return self.L.oz_tree_count_expanded(self.t)
 
 
 def play_game(game, H, W, k, transform_types, max_playout, dirichlet_before, max_turn,
-              ev, rng, d_alpha=0.03, d_epsilon=0.25, max_plies=None):
+              ev, rng, d_alpha=0.03, d_epsilon=0.25, max_plies=None, real64=False):
     cfg = OzGameCfg(GAME_IDS.get(game, game), H, W, k, transform_types, max_playout,
                     dirichlet_before, max_turn, d_alpha, d_epsilon)
     O = H * W + (0 if GAME_IDS.get(game, game) == MNK else 1)
@@ -237,7 +246,7 @@ def play_game(game, H, W, k, transform_types, max_playout, dirichlet_before, max
     tr.moves = moves.ctypes.data_as(C.POINTER(C.c_int16))
     tr.visits = visits.ctypes.data_as(C.POINTER(C.c_int32))
     evp = ev if isinstance(ev, C.c_void_p) else C.cast(ev, C.c_void_p)
-    rc = lib().oz_play_game(C.byref(cfg), evp, None, C.byref(rng.r), C.byref(tr), max_plies)
+    rc = lib(real64).oz_play_game(C.byref(cfg), evp, None, C.byref(rng.r), C.byref(tr), max_plies)
     if rc != 0:
         raise RuntimeError("oracle: RNG replay stream underflow")
     n = tr.n_plies

@@ -81,9 +81,12 @@ def test_fake_eval_c_matches_numpy():
 def _replay_search(g):
     game, H, W, k, O = str(g["game"]), int(g["H"]), int(g["W"]), int(g["k"]), int(g["O"])
     rng = oz.Rng(tids=g["tids"], etas=g["etas"], unis=g["unis"])
-    ev = oz.fn_ptr("oz_fake_eval")
+    evaluator = str(g["evaluator"]) if "evaluator" in g else "fake32"
+    real64 = evaluator != "fake32"            # float64 evaluator -> the float64 build of the oracle
+    bits = np.uint64 if real64 else np.uint32
+    ev = oz.fn_ptr("oz_uniform_eval" if evaluator == "uniform" else "oz_fake_eval", real64)
     st = oz.State(game, H, W, k)
-    trees = [oz.Tree(O, int(g["transform_types"]), float(g["d_alpha"]), float(g["d_epsilon"])) for _ in range(2)]
+    trees = [oz.Tree(O, int(g["transform_types"]), float(g["d_alpha"]), float(g["d_epsilon"]), real64) for _ in range(2)]
     cur = 0
     evals = 0
     for ply in range(len(g["moves"])):
@@ -97,8 +100,8 @@ def _replay_search(g):
         assert len(a) == nc, (ply, len(a), nc)
         assert np.array_equal(a, g["acts"][ply][:nc]), ply
         assert np.array_equal(n, g["N"][ply][:nc]), ply
-        assert np.array_equal(w.view(np.uint32), g["Wv"][ply][:nc].view(np.uint32)), ply
-        assert np.array_equal(p.view(np.uint32), g["P"][ply][:nc].view(np.uint32)), ply
+        assert np.array_equal(w.view(bits), g["Wv"][ply][:nc].view(bits)), ply
+        assert np.array_equal(p.view(bits), g["P"][ply][:nc].view(bits)), ply
         assert trees[cur].root_visits() == g["rootN"][ply]
         assert evals == g["cum_evals"][ply]
         assert rng.r.i_tids == g["cum_tids"][ply] and rng.r.i_etas == g["cum_etas"][ply]
@@ -114,7 +117,7 @@ def _replay_search(g):
     return st
 
 
-@pytest.mark.parametrize("name", golden_names("search_"))
+@pytest.mark.parametrize("name", golden_names("search_") + golden_names("search64_"))
 def test_search_trace(name):
     g = load_golden(name)
     st = _replay_search(g)
