@@ -24,6 +24,7 @@ class AzConfig(C.Structure):
         ("tree_edge_cap", C.c_int32), ("tree_block_cap", C.c_int32), ("max_depth", C.c_int32),
         ("rng_replay", C.c_int32), ("seed", C.c_uint64), ("record_trajectories", C.c_int32),
         ("num_blocks", C.c_int32), ("channels", C.c_int32), ("tower_dtype", C.c_int32), ("device", C.c_int32),
+        ("search_f64", C.c_int32),
     ]
 
 
@@ -87,6 +88,9 @@ SIGNATURES = {
     "az_rng_cursor": (_I, [_P, _I, _P, _P, _P]),
     "az_tower_blob_floats": (C.c_size_t, [_P]),
     "az_tower_load_weights": (_I, [_P, _P, C.c_size_t]),
+    "az_search_step_finish_f64": (_I, [_P, _P, _P]),
+    "az_selfplay_finish_f64": (_I, [_P, _P, _P]),
+    "az_search_root_stats_f64": (_I, [_P, _I, _I, _P, _P, _P, _P, _P]),
     "az_tower_load_weights_net": (_I, [_P, _I, _P, C.c_size_t]),
     "az_match_assign": (_I, [_P, _P, _I, _P]),
     "az_tower_forward": (_I, [_P, _P, _I, _P, _P]),

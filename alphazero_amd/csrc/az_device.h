@@ -68,11 +68,14 @@ struct Dev {
     int8_t *path_player; // [G][MAXD]
     uint8_t *leaf_mask;  // [G][AZ_OP]
     int8_t *planes;      // [G][17][NC]
-    float *priors;       // [G][O]
-    float *values;       // [G]
+    // search statistics and evaluator outputs are float32, or float64 when f64 is set (an evaluator that returns
+    // Python floats / float64 makes every intermediate of the reference's search a double): R = float | double
+    int f64;
+    void *priors;        // R [G][O]
+    void *values;        // R [G]
     // trees [2G]
-    int32_t *rootN; float *rootW; float *rootP; int32_t *rootBlock; int32_t *nBlocks; int32_t *nEdges;
-    int32_t *eN; float *eW; float *eP; int32_t *eChild; int16_t *eAct;       // [2G][EC]
+    int32_t *rootN; void *rootW; void *rootP; int32_t *rootBlock; int32_t *nBlocks; int32_t *nEdges;   // rootW, rootP: R
+    int32_t *eN; void *eW; void *eP; int32_t *eChild; int16_t *eAct;       // [2G][EC]; eW, eP: R
     int32_t *bStart, *bCount, *bOwner, *bParent, *bMap, *bShift;             // [2G][BC]
     int32_t *pending;    // [2G] move to re-root with, NOMOVE = none
     // rng

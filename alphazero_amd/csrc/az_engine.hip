@@ -160,12 +160,15 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     A(path_player, int8_t, (size_t)G * D.MAXD);
     A(leaf_mask, uint8_t, (size_t)G * AZ_OP);
     A(planes, int8_t, (size_t)G * 17 * NC + 64);
-    A(priors, float, (size_t)G * O);
-    A(values, float, G);
+    D.f64 = cfg->search_f64 ? 1 : 0;
+    const size_t rs = D.f64 ? 8 : 4;  // bytes of one search statistic
+#define AR(field, n) ok = ok && ((D.field = dalloc<char>(h, (size_t)(n) * rs)) != nullptr)
+    AR(priors, (size_t)G * O);
+    AR(values, G);
     const size_t T = 2 * (size_t)G;
-    A(rootN, int32_t, T); A(rootW, float, T); A(rootP, float, T); A(rootBlock, int32_t, T);
+    A(rootN, int32_t, T); AR(rootW, T); AR(rootP, T); A(rootBlock, int32_t, T);
     A(nBlocks, int32_t, T); A(nEdges, int32_t, T); A(pending, int32_t, T);
-    A(eN, int32_t, T * D.EC); A(eW, float, T * D.EC); A(eP, float, T * D.EC);
+    A(eN, int32_t, T * D.EC); AR(eW, T * D.EC); AR(eP, T * D.EC);
     A(eChild, int32_t, T * D.EC); A(eAct, int16_t, T * D.EC);
     A(bStart, int32_t, T * D.BC); A(bCount, int32_t, T * D.BC); A(bOwner, int32_t, T * D.BC);
     A(bParent, int32_t, T * D.BC); A(bMap, int32_t, T * D.BC); A(bShift, int32_t, T * D.BC);
@@ -178,6 +181,7 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     A(tr_winner, int32_t, G);
     A(ctr, unsigned long long, C_N);
 #undef A
+#undef AR
     const size_t stn = std::max(G, 64);
     ok = ok && (h->st_a = dalloc<int32_t>(h, stn)) && (h->st_b = dalloc<int32_t>(h, stn)) &&
          (h->st_c = dalloc<int32_t>(h, stn)) && (h->st_d = dalloc<int32_t>(h, stn)) && (h->st_e = dalloc<int32_t>(h, stn));
@@ -396,7 +400,8 @@ extern "C" int az_search_begin(az_engine *h, const int32_t *slots, int32_t n, co
 static int launch_select(az_engine *h)
 {
     HIPCHK(hipMemsetAsync(h->D.ctr + C_NLEAVES, 0, sizeof(unsigned long long), h->stream));
-    hipLaunchKernelGGL(k_select, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
+    if (h->D.f64) hipLaunchKernelGGL(k_select<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
+    else hipLaunchKernelGGL(k_select<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
     HIPCHK(hipGetLastError());
     return AZ_OK;
 }
@@ -428,15 +433,20 @@ extern "C" int az_leaf_batch(az_engine *h, int8_t *planes, uint8_t *valid)
     return AZ_OK;
 }
 
-static int evaluate(az_engine *h, const float *priors, const float *values)
+// priors / values: host arrays of the engine's statistic type (f64 says which the caller passed), or NULL = run the tower
+static int evaluate(az_engine *h, const void *priors, const void *values, int f64 = 0)
 {
     const int G = h->D.G, O = h->D.geo.O;
     if ((priors == nullptr) != (values == nullptr)) return set_err(h, AZ_ERR_ARG, "priors and values must both be given or both NULL");
     if (priors) {
-        HIPCHK(hipMemcpyAsync(h->D.priors, priors, sizeof(float) * (size_t)G * O, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->D.values, values, sizeof(float) * G, hipMemcpyHostToDevice, h->stream));
+        if (f64 != h->D.f64)
+            return set_err(h, AZ_ERR_ARG, h->D.f64 ? "engine searches in float64: use the _f64 entry point" : "engine searches in float32: use the float entry point");
+        const size_t rs = h->D.f64 ? 8 : 4;
+        HIPCHK(hipMemcpyAsync(h->D.priors, priors, rs * (size_t)G * O, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->D.values, values, rs * G, hipMemcpyHostToDevice, h->stream));
         return AZ_OK;
     }
+    if (h->D.f64) return set_err(h, AZ_ERR_ARG, "a float64 search takes injected priors only: the tower's outputs are float32");
     if (!h->tower || !tower_ready(h->tower)) return set_err(h, AZ_ERR_NO_WEIGHTS, "no tower weights loaded and no priors injected");
     std::string terr;
     if (h->two_nets) {
@@ -448,7 +458,7 @@ static int evaluate(az_engine *h, const float *priors, const float *values)
         Tower *tw[2] = {h->tower, h->tower2};
         for (int net = 0; net < 2; net++) {
             if (cnt[net] == 0) continue;
-            if (tower_forward(tw[net], h->D.planes, cnt[net], h->D.priors, h->D.values, h->stream, terr, h->net_rows + (size_t)net * G) != 0) {
+            if (tower_forward(tw[net], h->D.planes, cnt[net], (float *)h->D.priors, (float *)h->D.values, h->stream, terr, h->net_rows + (size_t)net * G) != 0) {
                 h->error = "tower: " + terr;
                 return AZ_ERR_HIP;
             }
@@ -457,7 +467,7 @@ static int evaluate(az_engine *h, const float *priors, const float *values)
         }
         return AZ_OK;
     }
-    if (tower_forward(h->tower, h->D.planes, G, h->D.priors, h->D.values, h->stream, terr) != 0) {
+    if (tower_forward(h->tower, h->D.planes, G, (float *)h->D.priors, (float *)h->D.values, h->stream, terr) != 0) {
         h->error = "tower: " + terr;
         return AZ_ERR_HIP;
     }
@@ -466,22 +476,50 @@ static int evaluate(az_engine *h, const float *priors, const float *values)
     return AZ_OK;
 }
 
-extern "C" int az_search_step_finish(az_engine *h, const float *priors, const float *values)
+static int step_finish(az_engine *h, const void *priors, const void *values, int f64);
+
+extern "C" int az_search_step_finish(az_engine *h, const float *priors, const float *values) { return step_finish(h, priors, values, 0); }
+extern "C" int az_search_step_finish_f64(az_engine *h, const double *priors, const double *values)
+{
+    if (!priors || !values) return AZ_ERR_ARG;
+    return step_finish(h, priors, values, 1);
+}
+
+static int step_finish(az_engine *h, const void *priors, const void *values, int f64)
 {
     if (!h) return AZ_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device));
-    int rc = evaluate(h, priors, values);
+    int rc = evaluate(h, priors, values, f64);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_finish, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
+    if (h->D.f64) hipLaunchKernelGGL(k_finish<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
+    else hipLaunchKernelGGL(k_finish<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
     HIPCHK(hipGetLastError());
     h->steps++;
     return check_slot_errors(h);
 }
 
+static int root_stats(az_engine *h, int32_t slot, int32_t side, int32_t *actions, int32_t *visits, void *total_value, void *prior,
+                      int32_t *root_visits, int f64);
+
 extern "C" int az_search_root_stats(az_engine *h, int32_t slot, int32_t side, int32_t *actions, int32_t *visits,
                                     float *total_value, float *prior, int32_t *root_visits)
 {
+    return root_stats(h, slot, side, actions, visits, total_value, prior, root_visits, 0);
+}
+
+extern "C" int az_search_root_stats_f64(az_engine *h, int32_t slot, int32_t side, int32_t *actions, int32_t *visits,
+                                        double *total_value, double *prior, int32_t *root_visits)
+{
+    return root_stats(h, slot, side, actions, visits, total_value, prior, root_visits, 1);
+}
+
+static int root_stats(az_engine *h, int32_t slot, int32_t side, int32_t *actions, int32_t *visits, void *total_value, void *prior,
+                      int32_t *root_visits, int f64)
+{
     if (!h || slot < 0 || slot >= h->D.G || side < 0 || side > 1) return AZ_ERR_ARG;
+    if ((total_value || prior) && f64 != h->D.f64)
+        return set_err(h, AZ_ERR_ARG, h->D.f64 ? "engine searches in float64: use az_search_root_stats_f64" : "engine searches in float32: use az_search_root_stats");
+    const size_t rs = h->D.f64 ? 8 : 4;
     HIPCHK(hipSetDevice(h->cfg.device));
     const Dev &D = h->D;
     const int t = 2 * slot + side;
@@ -496,8 +534,8 @@ extern "C" int az_search_root_stats(az_engine *h, int32_t slot, int32_t side, in
     HIPCHK(hipMemcpy(&n, D.bCount + (size_t)t * D.BC + rb, 4, hipMemcpyDeviceToHost));
     const size_t e0 = (size_t)t * D.EC + start;
     if (visits) HIPCHK(hipMemcpy(visits, D.eN + e0, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-    if (total_value) HIPCHK(hipMemcpy(total_value, D.eW + e0, sizeof(float) * n, hipMemcpyDeviceToHost));
-    if (prior) HIPCHK(hipMemcpy(prior, D.eP + e0, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (total_value) HIPCHK(hipMemcpy(total_value, (const char *)D.eW + e0 * rs, rs * n, hipMemcpyDeviceToHost));
+    if (prior) HIPCHK(hipMemcpy(prior, (const char *)D.eP + e0 * rs, rs * n, hipMemcpyDeviceToHost));
     if (actions) {
         std::vector<int16_t> a(n);
         HIPCHK(hipMemcpy(a.data(), D.eAct + e0, sizeof(int16_t) * n, hipMemcpyDeviceToHost));
@@ -527,7 +565,8 @@ static int advance(az_engine *h, const int32_t *slots, int n, const int32_t *mov
     if ((rc = up(h, h->st_a, slots, n)) || (rc = up(h, h->st_b, moves, n))) return rc;
     hipLaunchKernelGGL(k_set_pending, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->D, (const int32_t *)h->st_a, n,
                        (const int32_t *)h->st_b, side_sel);
-    hipLaunchKernelGGL(k_reroot, dim3(2 * h->D.G), dim3(64), 0, h->stream, h->D);
+    if (h->D.f64) hipLaunchKernelGGL(k_reroot<double>, dim3(2 * h->D.G), dim3(64), 0, h->stream, h->D);
+    else hipLaunchKernelGGL(k_reroot<float>, dim3(2 * h->D.G), dim3(64), 0, h->stream, h->D);
     HIPCHK(hipStreamSynchronize(h->stream));
     return AZ_OK;
 }
@@ -568,9 +607,11 @@ extern "C" int az_selfplay_start(az_engine *h)
 
 static void launch_tail(az_engine *h)
 {
-    hipLaunchKernelGGL(k_finish, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
+    if (h->D.f64) hipLaunchKernelGGL(k_finish<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
+    else hipLaunchKernelGGL(k_finish<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
     hipLaunchKernelGGL(k_move, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
-    hipLaunchKernelGGL(k_reroot, dim3(2 * h->D.G), dim3(64), 0, h->stream, h->D);
+    if (h->D.f64) hipLaunchKernelGGL(k_reroot<double>, dim3(2 * h->D.G), dim3(64), 0, h->stream, h->D);
+    else hipLaunchKernelGGL(k_reroot<float>, dim3(2 * h->D.G), dim3(64), 0, h->stream, h->D);
 }
 
 extern "C" int az_selfplay_run(az_engine *h, int32_t n_rounds)
@@ -608,11 +649,20 @@ extern "C" int az_selfplay_select(az_engine *h, int32_t *n_leaves)
     return az_search_step_select(h, n_leaves);
 }
 
-extern "C" int az_selfplay_finish(az_engine *h, const float *priors, const float *values)
+static int selfplay_finish(az_engine *h, const void *priors, const void *values, int f64);
+
+extern "C" int az_selfplay_finish(az_engine *h, const float *priors, const float *values) { return selfplay_finish(h, priors, values, 0); }
+extern "C" int az_selfplay_finish_f64(az_engine *h, const double *priors, const double *values)
+{
+    if (!priors || !values) return AZ_ERR_ARG;
+    return selfplay_finish(h, priors, values, 1);
+}
+
+static int selfplay_finish(az_engine *h, const void *priors, const void *values, int f64)
 {
     if (!h) return AZ_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device));
-    int rc = evaluate(h, priors, values);
+    int rc = evaluate(h, priors, values, f64);
     if (rc) return rc;
     launch_tail(h);
     HIPCHK(hipGetLastError());
@@ -770,7 +820,7 @@ extern "C" int az_tower_forward(az_engine *h, const int8_t *planes, int32_t B, f
     for (int b0 = 0; b0 < B; b0 += G) {
         int nb = std::min(G, B - b0);
         HIPCHK(hipMemcpyAsync(h->D.planes, planes + (size_t)b0 * 17 * NC, (size_t)nb * 17 * NC, hipMemcpyHostToDevice, h->stream));
-        if (tower_forward(h->tower, h->D.planes, nb, h->D.priors, h->D.values, h->stream, terr) != 0) {
+        if (tower_forward(h->tower, h->D.planes, nb, (float *)h->D.priors, (float *)h->D.values, h->stream, terr) != 0) {
             h->error = "tower: " + terr;
             return AZ_ERR_HIP;
         }

@@ -64,14 +64,16 @@ __device__ double gamma_small(double alpha, unsigned long long key)
 
 // P <- (1-eps)*P + eps*eta over the root's children in insertion order
 // (search/mcts.py:285-291; eta is NOT normalised, math_helper.py:13-17)
+template <typename R>
 __device__ void apply_noise(const Dev &D, int g, int t)
 {
+    R *const eP = static_cast<R *>(D.eP);
     const int lane = lane_id();
     int rb = D.rootBlock[t];
     if (rb < 0) return;
     size_t tb = (size_t)t * D.EC, bb = (size_t)t * D.BC;
     int start = D.bStart[bb + rb], n = D.bCount[bb + rb];
-    float keep = (float)(1.0 - D.d_epsilon);
+    R keep = (R)(1.0 - D.d_epsilon);
     long long base = 0;
     unsigned long long key = 0;
     if (D.rng_replay) {
@@ -84,9 +86,9 @@ __device__ void apply_noise(const Dev &D, int g, int t)
     }
     for (int c = lane; c < n; c += AZ_WAVE) {
         double eta = D.rng_replay ? D.re[g][base + c] : gamma_small(D.d_alpha, key + 1000ULL * (unsigned long long)(c + 1));
-        float p = D.eP[tb + start + c];
-        float a = keep * p;
-        D.eP[tb + start + c] = a + (float)(D.d_epsilon * eta);
+        R p = eP[tb + start + c];
+        R a = keep * p;
+        eP[tb + start + c] = a + (R)(D.d_epsilon * eta);
     }
     WSYNC();
 }
@@ -96,9 +98,12 @@ __device__ void apply_noise(const Dev &D, int g, int t)
 // (search/mcts.py:173-217, :261-280)
 // ---------------------------------------------------------------------------
 
+template <typename R>
 __global__ __launch_bounds__(64) void k_select(Dev D)
 {
     __shared__ WLds L;
+    const R *const eW = static_cast<const R *>(D.eW);
+    const R *const eP = static_cast<const R *>(D.eP);
     const int g = blockIdx.x;
     const int lane = lane_id();
     const Geo G = D.geo;
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(64) void k_select(Dev D)
         if (D.rootBlock[t] < 0) {
             root_expand = 1;
         } else {
-            if (D.dflag[g]) apply_noise(D, g, t);
+            if (D.dflag[g]) apply_noise<R>(D, g, t);
             phase = PH_IN_SEARCH;
             if (lane == 0) { D.phase[g] = PH_IN_SEARCH; D.pdone[g] = 0; }
             if (D.max_playout == 0) {
@@ -140,23 +145,23 @@ __global__ __launch_bounds__(64) void k_select(Dev D)
         int parentN = rootN;
         while (blk >= 0) {
             int start = D.bStart[bb + blk], n = D.bCount[bb + blk];
-            // Q+U in float32, left to right as mcts.py:88-90; first maximum wins
-            float sq = (float)sqrt((double)parentN);
-            float bv = -INFINITY;
+            // Q+U in the evaluator's precision, left to right as mcts.py:88-90; first maximum wins
+            R sq = (R)sqrt((double)parentN);
+            R bv = -INFINITY;
             int bi = 0x7fffffff;
             for (int c = lane; c < n; c += AZ_WAVE) {
                 int N = D.eN[tb + start + c];
-                float Wv = D.eW[tb + start + c], P = D.eP[tb + start + c];
-                float u = 5.0f * P;
+                R Wv = eW[tb + start + c], P = eP[tb + start + c];
+                R u = (R)5.0 * P;
                 u = u * sq;
-                u = u / (1.0f + (float)N);
-                float q = N == 0 ? 0.0f : Wv / (float)N;
-                float v = q + u;
+                u = u / ((R)1.0 + (R)N);
+                R q = N == 0 ? (R)0.0 : Wv / (R)N;
+                R v = q + u;
                 if (v > bv) { bv = v; bi = c; }
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
-                float ov = __shfl_xor(bv, o, 64);
+                R ov = __shfl_xor(bv, o, 64);
                 int oi = __shfl_xor(bi, o, 64);
                 if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
             }
@@ -213,8 +218,12 @@ __global__ __launch_bounds__(64) void k_select(Dev D)
 // finish: expand or terminal value, then backup (mcts.py:217-232, 196-202, 283)
 // ---------------------------------------------------------------------------
 
+template <typename R>
 __global__ __launch_bounds__(64) void k_finish(Dev D)
 {
+    R *const eW = static_cast<R *>(D.eW);
+    R *const eP = static_cast<R *>(D.eP);
+    R *const rootW = static_cast<R *>(D.rootW);
     const int g = blockIdx.x;
     const int lane = lane_id();
     const Geo G = D.geo;
@@ -226,9 +235,9 @@ __global__ __launch_bounds__(64) void k_finish(Dev D)
     const int node = D.leaf_node[g];
     const int player = D.leaf_player[g];
     const int tid = D.leaf_tid[g];
-    float v = D.values[g];
+    R v = static_cast<const R *>(D.values)[g];
     const uint8_t *mask = D.leaf_mask + (size_t)g * AZ_OP;
-    const float *pri = D.priors + (size_t)g * G.O;
+    const R *pri = static_cast<const R *>(D.priors) + (size_t)g * G.O;
     WSYNC();
     const int expandable = root_expand ? 1 : !D.leaf_end[g];
     if (expandable) {
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(64) void k_finish(Dev D)
             int pos = off + __popcll(bal & ((1ULL << lane) - 1ULL));
             if (legal) {
                 size_t e = tb + start + pos;
-                D.eN[e] = 0; D.eW[e] = 0.0f; D.eP[e] = pri[i]; D.eChild[e] = -1; D.eAct[e] = (int16_t)a;
+                D.eN[e] = 0; eW[e] = (R)0.0; eP[e] = pri[i]; D.eChild[e] = -1; D.eAct[e] = (int16_t)a;
             }
             off += __popcll(bal);
         }
@@ -270,19 +279,19 @@ __global__ __launch_bounds__(64) void k_finish(Dev D)
                 atomicAdd(&D.ctr[C_EDGES], (unsigned long long)n);
             }
             // node.update(value): raw value at the root, -player*value below it
-            float add = root_expand ? v : (float)(-player) * v;
-            if (node == NODE_ROOT) D.rootW[t] += add; else D.eW[tb + node] += add;
+            R add = root_expand ? v : (R)(-player) * v;
+            if (node == NODE_ROOT) rootW[t] += add; else eW[tb + node] += add;
         }
     } else {
-        v = (float)D.leaf_winner[g];  // value = state.get_winner()
+        v = (R)D.leaf_winner[g];  // value = state.get_winner()
         if (lane == 0) {
-            float add = (float)(-player) * v;
-            if (node == NODE_ROOT) D.rootW[t] += add; else D.eW[tb + node] += add;
+            R add = (R)(-player) * v;
+            if (node == NODE_ROOT) rootW[t] += add; else eW[tb + node] += add;
         }
     }
     WSYNC();
     if (root_expand) {
-        if (D.dflag[g]) apply_noise(D, g, t);
+        if (D.dflag[g]) apply_noise<R>(D, g, t);
         if (lane == 0) {
             D.pdone[g] = 0;
             D.phase[g] = D.max_playout == 0 ? PH_SEARCH_DONE : PH_IN_SEARCH;
@@ -293,8 +302,8 @@ __global__ __launch_bounds__(64) void k_finish(Dev D)
     int plen = D.path_len[g];
     for (int d = lane; d < plen; d += AZ_WAVE) {
         int nd = D.path_node[(size_t)g * D.MAXD + d];
-        float add = (float)(-(int)D.path_player[(size_t)g * D.MAXD + d]) * v;
-        if (nd == NODE_ROOT) D.rootW[t] += add; else D.eW[tb + nd] += add;
+        R add = (R)(-(int)D.path_player[(size_t)g * D.MAXD + d]) * v;
+        if (nd == NODE_ROOT) rootW[t] += add; else eW[tb + nd] += add;
     }
     if (lane == 0) {
         int pd = D.pdone[g] + 1;
@@ -398,8 +407,13 @@ __global__ __launch_bounds__(64) void k_move(Dev D)
 // every block only ever moves towards lower addresses)
 // ---------------------------------------------------------------------------
 
+template <typename R>
 __global__ __launch_bounds__(64) void k_reroot(Dev D)
 {
+    R *const eW = static_cast<R *>(D.eW);
+    R *const eP = static_cast<R *>(D.eP);
+    R *const rootW = static_cast<R *>(D.rootW);
+    R *const rootP = static_cast<R *>(D.rootP);
     const int t = blockIdx.x;
     const int lane = lane_id();
     const int mv = D.pending[t];
@@ -420,17 +434,17 @@ __global__ __launch_bounds__(64) void k_reroot(Dev D)
     }
     if (found < 0) {  // MCTreeNode(None, 1.0)
         if (lane == 0) {
-            D.rootN[t] = 0; D.rootW[t] = 0.0f; D.rootP[t] = 1.0f;
+            D.rootN[t] = 0; rootW[t] = (R)0.0; rootP[t] = (R)1.0;
             D.rootBlock[t] = -1; D.nBlocks[t] = 0; D.nEdges[t] = 0;
         }
         return;
     }
     const int r = D.eChild[tb + found];
     const int nN = D.eN[tb + found];
-    const float nW = D.eW[tb + found], nP = D.eP[tb + found];
+    const R nW = eW[tb + found], nP = eP[tb + found];
     const int nb = D.nBlocks[t];
     WSYNC();
-    if (lane == 0) { D.rootN[t] = nN; D.rootW[t] = nW; D.rootP[t] = nP; }
+    if (lane == 0) { D.rootN[t] = nN; rootW[t] = nW; rootP[t] = nP; }
     if (r < 0) {
         if (lane == 0) { D.rootBlock[t] = -1; D.nBlocks[t] = 0; D.nEdges[t] = 0; }
         return;
@@ -492,16 +506,16 @@ __global__ __launch_bounds__(64) void k_reroot(Dev D)
         WSYNC();
         for (int c0 = 0; c0 < cnt; c0 += AZ_WAVE) {
             int c = c0 + lane;
-            int N = 0, ch = -1; float Wv = 0, P = 0; int16_t a = 0;
+            int N = 0, ch = -1; R Wv = 0, P = 0; int16_t a = 0;
             if (c < cnt) {
                 size_t e = tb + os + c;
-                N = D.eN[e]; Wv = D.eW[e]; P = D.eP[e]; ch = D.eChild[e]; a = D.eAct[e];
+                N = D.eN[e]; Wv = eW[e]; P = eP[e]; ch = D.eChild[e]; a = D.eAct[e];
                 if (ch >= 0) ch = D.bMap[bb + ch];
             }
             WSYNC();
             if (c < cnt) {
                 size_t e = tb + ns + c;
-                D.eN[e] = N; D.eW[e] = Wv; D.eP[e] = P; D.eChild[e] = ch; D.eAct[e] = a;
+                D.eN[e] = N; eW[e] = Wv; eP[e] = P; D.eChild[e] = ch; D.eAct[e] = a;
             }
             WSYNC();
         }
@@ -553,7 +567,9 @@ __global__ __launch_bounds__(64) void k_reset(Dev D, const int32_t *slots, int n
         D.automode[g] = automode; D.ply[g] = 0; D.err[g] = 0; D.leaf_valid[g] = 0; D.tr_winner[g] = 0;
         for (int k = 0; k < 2; k++) {
             int t = 2 * g + k;
-            D.rootN[t] = 0; D.rootW[t] = 0.0f; D.rootP[t] = 1.0f; D.rootBlock[t] = -1;
+            D.rootN[t] = 0; D.rootBlock[t] = -1;
+            if (D.f64) { static_cast<double *>(D.rootW)[t] = 0.0; static_cast<double *>(D.rootP)[t] = 1.0; }
+            else { static_cast<float *>(D.rootW)[t] = 0.0f; static_cast<float *>(D.rootP)[t] = 1.0f; }
             D.nBlocks[t] = 0; D.nEdges[t] = 0; D.pending[t] = NOMOVE;
         }
     }

@@ -35,13 +35,16 @@ class Engine:
     def __init__(self, game, board_height, board_width, k=0, n_slots=1, max_playout=0, transform_types=0,
                  dirichlet_before=30, max_turn=400, d_alpha=0.03, d_epsilon=0.25, tree_edge_cap=0, tree_block_cap=0,
                  max_depth=0, rng_replay=False, seed=0, record_trajectories=False, num_blocks=0, channels=256,
-                 tower_dtype="bf16", device=0):
+                 tower_dtype="bf16", device=0, search_f64=False):
         self._L = _lib.lib()
         cfg = AzConfig(GAME_IDS[game] if isinstance(game, str) else int(game), board_height, board_width, k, n_slots,
                        max_playout, transform_types, dirichlet_before, max_turn, d_alpha, d_epsilon, tree_edge_cap,
                        tree_block_cap, max_depth, int(rng_replay), seed, int(record_trajectories), num_blocks, channels,
-                       {"fp32": 0, "bf16": 1}[tower_dtype] if isinstance(tower_dtype, str) else int(tower_dtype), device)
+                       {"fp32": 0, "bf16": 1}[tower_dtype] if isinstance(tower_dtype, str) else int(tower_dtype), device,
+                       int(bool(search_f64)))
         self.cfg = cfg
+        # dtype of W / P / priors / values: float64 reproduces a search fed by a float64 evaluator (dummy_eval.py:26-28)
+        self.real = np.float64 if search_f64 else np.float32
         self._h = self._L.az_engine_create(C.byref(cfg))
         if not self._h:
             raise EngineError(-2, self._L.az_last_error(None).decode())
@@ -138,17 +141,18 @@ class Engine:
         if priors is None:
             self._ck(self._L.az_search_step_finish(self._h, None, None))
             return
-        p = np.ascontiguousarray(priors, np.float32)
-        v = np.ascontiguousarray(values, np.float32)
+        p = np.ascontiguousarray(priors, self.real)
+        v = np.ascontiguousarray(values, self.real)
         assert p.shape == (self.G, self.O) and v.shape == (self.G,)
-        self._ck(self._L.az_search_step_finish(self._h, p.ctypes.data, v.ctypes.data))
+        fn = self._L.az_search_step_finish_f64 if self.real is np.float64 else self._L.az_search_step_finish
+        self._ck(fn(self._h, p.ctypes.data, v.ctypes.data))
 
     def root_stats(self, slot, side):
         a = np.zeros(self.O, np.int32); n = np.zeros(self.O, np.int32)
-        w = np.zeros(self.O, np.float32); p = np.zeros(self.O, np.float32)
+        w = np.zeros(self.O, self.real); p = np.zeros(self.O, self.real)
         rn = C.c_int32(0)
-        c = self._ck(self._L.az_search_root_stats(self._h, slot, side, a.ctypes.data, n.ctypes.data, w.ctypes.data,
-                                                  p.ctypes.data, C.byref(rn)))
+        fn = self._L.az_search_root_stats_f64 if self.real is np.float64 else self._L.az_search_root_stats
+        c = self._ck(fn(self._h, slot, side, a.ctypes.data, n.ctypes.data, w.ctypes.data, p.ctypes.data, C.byref(rn)))
         return a[:c], n[:c], w[:c], p[:c], rn.value
 
     def choose(self, slot, side, u):
@@ -184,10 +188,11 @@ class Engine:
         if priors is None:
             self._ck(self._L.az_selfplay_finish(self._h, None, None))
             return
-        p = np.ascontiguousarray(priors, np.float32)
-        v = np.ascontiguousarray(values, np.float32)
+        p = np.ascontiguousarray(priors, self.real)
+        v = np.ascontiguousarray(values, self.real)
         assert p.shape == (self.G, self.O) and v.shape == (self.G,)
-        self._ck(self._L.az_selfplay_finish(self._h, p.ctypes.data, v.ctypes.data))
+        fn = self._L.az_selfplay_finish_f64 if self.real is np.float64 else self._L.az_selfplay_finish
+        self._ck(fn(self._h, p.ctypes.data, v.ctypes.data))
 
     def selfplay_status(self):
         plies = np.zeros(self.G, np.int32); done = np.zeros(self.G, np.int32)

@@ -78,8 +78,13 @@ class MCTSearch(object):
         tower_kw = {}
         if self._tower is not None:
             tower_kw = dict(num_blocks=self._tower.num_blocks, channels=self._tower.channels, tower_dtype=self._tower.dtype)
-        self._eng = Engine(n_slots=1, max_playout=max_playout, rng_replay=True, **kw, **tower_kw)
+        self._eng_kw = dict(n_slots=1, max_playout=max_playout, rng_replay=True, **kw)
+        self._eng = Engine(**self._eng_kw, **tower_kw)
         self._loaded_version = None
+        # Arithmetic of N/W/P follows the evaluator's output type, as NumPy's promotion makes it in the reference:
+        # float32 priors (the network) keep the search in float32, Python floats / float64 (DummyEvaluator) in
+        # float64.  Decided by the first evaluation of a host evaluator; the device tower is always float32.
+        self._f64 = False if self._tower is not None else None
 
     @property
     def _root(self):
@@ -113,13 +118,23 @@ class MCTSearch(object):
             while eng.step_select() > 0:
                 eng.step_finish()
             return
-        pri = np.zeros((1, self._O), np.float32)
-        val = np.zeros(1, np.float32)
         while eng.step_select() > 0:
             planes, _ = eng.leaf_batch()
             cand, value = self._evaluator(_LeafView(planes[0], self._H, self._W))
-            pri[0, :] = [p for _, p in cand]
-            val[0] = value
+            f64 = not isinstance(cand[0][1], np.float32)
+            if self._f64 is None:
+                self._f64 = f64
+                if f64:  # nothing is in the trees yet: restart this search on a float64 engine with the same draws
+                    eng.close()
+                    eng = self._eng = Engine(**self._eng_kw, search_f64=True)
+                    eng.state_copy(0, state._eng, state._slot, ref_semantics=False)
+                    eng.rng_inject(0, tids, etas, [])
+                    eng.search_begin([0], [0], [int(bool(dirichlet))])
+                    assert eng.step_select() > 0
+            elif f64 != self._f64:
+                raise TypeError("evaluator changed its output dtype between float32 and float64 within one search tree")
+            pri = np.array([[p for _, p in cand]], eng.real)
+            val = np.array([value], eng.real)
             eng.step_finish(pri, val)
 
     def _get_search_probs(self):

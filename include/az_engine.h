@@ -68,6 +68,9 @@ typedef struct az_config {
     int32_t channels;          /* 256 in the reference (model.py:47,55-56) */
     int32_t tower_dtype;       /* AZ_TOWER_FP32 / AZ_TOWER_BF16 */
     int32_t device;            /* HIP device ordinal */
+    int32_t search_f64;        /* 0: N/W/P arithmetic in float32 (a float32 evaluator: the network, nn_eval_parallel.py:75-92);
+                                  1: in float64 (an evaluator returning Python floats / float64: evaluator/dummy_eval.py:26-28).
+                                  With 1 the tower cannot feed the search; use the *_f64 entry points */
 } az_config;
 
 /* Fixed-layout copy of one game state (attributes of env/*.py GameState). */
@@ -180,6 +183,13 @@ int az_rng_cursor(az_engine *h, int32_t slot, int64_t *i_tids, int64_t *i_etas, 
 size_t az_tower_blob_floats(az_engine *h);      /* float32 count of the folded-weight blob */
 /* folded float32 weights, layout documented in alphazero_amd/network/model.py */
 int az_tower_load_weights(az_engine *h, const float *blob, size_t n_floats);
+/* float64 forms of the three calls that carry W / P / priors / values, for engines created with search_f64 = 1
+ * (the float32 forms return AZ_ERR_ARG on such an engine, and these on a float32 engine) */
+int az_search_step_finish_f64(az_engine *h, const double *priors, const double *values);
+int az_selfplay_finish_f64(az_engine *h, const double *priors, const double *values);
+int az_search_root_stats_f64(az_engine *h, int32_t slot, int32_t side, int32_t *actions, int32_t *visits,
+                             double *total_value, double *prior, int32_t *root_visits);
+
 /* Gating matches between two weight sets (train/parallel/evaluator.py:70-98: Game(nn_eval_chal, nn_eval_best, ...) or
  * the two swapped).  Network 0 is the one az_tower_load_weights fills; network 1 is created on first load.
  * az_match_assign: in slot slots[i] the side that moves first (player_1, Black) is evaluated by network

@@ -219,3 +219,39 @@ def test_nn_evaluator_player_and_batched_selfplay():
         assert np.allclose(p.sum(axis=1), 1.0) and set(np.unique(r)) <= {-1.0, 1.0}
         assert np.all(s[0][:16] == 0) and np.all(s[0][16] == 1)
     mnk.game_config.update(board_height=6, board_width=5, k=4)
+
+
+def test_dummy_evaluator_search_runs_in_float64_like_the_reference():
+    """DummyEvaluator returns np.float64 priors and the Python int 0 (evaluator/dummy_eval.py:26-28), which makes
+    every N/W/P intermediate of the reference's search a double: the drop-in MCTSearch must notice and reproduce the
+    reference's trace (fixture search64_go9_uniform, seed 31) bit for bit."""
+    g = load_golden("search64_go9_uniform")
+    H, W, O = int(g["H"]), int(g["W"]), int(g["O"])
+    cfg = _cfg("go", H, W, O, int(g["transform_types"]))
+    import alphazero_amd.env.go as go
+    from alphazero_amd.evaluator.dummy_eval import DummyEvaluator
+    from alphazero_amd.player.mcts_player import Player
+    ev = DummyEvaluator(cfg)
+    saved = _install_seeded_draws(31)
+    try:
+        p1 = Player(ev, cfg, {"max_playout": int(g["max_playout"])})
+        p2 = Player(ev, cfg, {"max_playout": int(g["max_playout"])})
+        st = go.GameState(size=H)
+        cur = p1
+        for ply in range(len(g["moves"])):
+            move, probs = cur.think(st, st.turns <= int(g["dirichlet_before"]))
+            eng = cur.mcts._eng
+            assert eng.real is np.float64
+            a, n, w, p, rootN = eng.root_stats(0, 0)
+            nc = int(g["n_children"][ply])
+            assert np.array_equal(a, g["acts"][ply][:nc]) and np.array_equal(n, g["N"][ply][:nc]), ply
+            assert np.array_equal(w.view(np.uint64), g["Wv"][ply][:nc].view(np.uint64)), ply
+            assert np.array_equal(p.view(np.uint64), g["P"][ply][:nc].view(np.uint64)), ply
+            assert st._a2i(move) == g["moves"][ply], ply
+            st.do_move(move)
+            p1.ack(move)
+            p2.ack(move)
+            cur = p2 if cur is p1 else p1
+    finally:
+        _restore(saved)
+    assert np.array_equal(st.board, g["final_board"])

@@ -20,7 +20,18 @@ def _engine_for(g, n_slots=1, record=False, **kw):
                   record_trajectories=record, **kw)
 
 
-def _run_search(eng):
+def _evaluate(planes, O, evaluator):
+    """The fixture's evaluator: the float32 hash, the same hash widened to float64, or DummyEvaluator's
+    float64 uniform priors with value 0 (evaluator/dummy_eval.py:26-28)."""
+    if evaluator == "uniform":
+        return np.full((planes.shape[0], O), 1 / O), np.zeros(planes.shape[0])
+    pri, v = fake_eval_planes(planes, O)
+    if evaluator == "fake":
+        return pri.astype(np.float64), v.astype(np.float64)
+    return pri, v
+
+
+def _run_search(eng, evaluator="fake32"):
     O = eng.O
     rounds = 0
     while True:
@@ -28,16 +39,20 @@ def _run_search(eng):
         if n == 0:
             break
         planes, valid = eng.leaf_batch()
-        pri, v = fake_eval_planes(planes, O)
+        pri, v = _evaluate(planes, O, evaluator)
         eng.step_finish(pri, v)
         rounds += 1
     return rounds
 
 
-@pytest.mark.parametrize("name", golden_names("search_"))
+@pytest.mark.parametrize("name", golden_names("search_") + golden_names("search64_"))
 def test_search_trace_manual_api(name):
     g = load_golden(name)
-    eng = _engine_for(g)
+    evaluator = str(g["evaluator"]) if "evaluator" in g else "fake32"
+    f64 = evaluator != "fake32"   # float64 evaluator: the whole search runs in float64, W and P compared as 64-bit patterns
+    bits = np.uint64 if f64 else np.uint32
+    eng = _engine_for(g, search_f64=f64)
+    assert eng.real is (np.float64 if f64 else np.float32)
     eng.rng_inject(0, g["tids"], g["etas"], g["unis"])
     side, evals, ui = 0, 0, 0
     for ply in range(len(g["moves"])):
@@ -45,14 +60,14 @@ def test_search_trace_manual_api(name):
         st = eng.state_get(0)
         dirichlet = st.turns <= int(g["dirichlet_before"])
         eng.search_begin([0], [side], [int(dirichlet)])
-        evals += _run_search(eng)
+        evals += _run_search(eng, evaluator)
         a, n, w, p, rootN = eng.root_stats(0, side)
         nc = int(g["n_children"][ply])
         assert len(a) == nc, (ply, len(a), nc)
         assert np.array_equal(a, g["acts"][ply][:nc]), ply
         assert np.array_equal(n, g["N"][ply][:nc]), ply
-        assert np.array_equal(w.view(np.uint32), g["Wv"][ply][:nc].view(np.uint32)), ply
-        assert np.array_equal(p.view(np.uint32), g["P"][ply][:nc].view(np.uint32)), ply
+        assert np.array_equal(w.view(bits), g["Wv"][ply][:nc].view(bits)), ply
+        assert np.array_equal(p.view(bits), g["P"][ply][:nc].view(bits)), ply
         assert rootN == g["rootN"][ply]
         assert evals == g["cum_evals"][ply]
         it, ie, iu = eng.rng_cursor(0)
