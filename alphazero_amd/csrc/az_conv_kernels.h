@@ -37,7 +37,7 @@ __global__ void k_planes_to_nhwc(const int8_t *planes, T *X0, int H, int W, cons
     // board b of the batch is row rows[b] of `planes` (rows == nullptr: row b)
     const int b = blockIdx.x, HW = H * W, PP = (H + 2) * (W + 2);
     const int8_t *src = planes + (size_t)(rows ? rows[b] : b) * 17 * HW;
-    for (int idx = threadIdx.x; idx < HW * CIN0; idx += blockDim.x) {
+    for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < HW * CIN0; idx += blockDim.x * gridDim.y) {
         int pix = idx / CIN0, c = idx - pix * CIN0;
         int y = pix / W, x = pix - y * W;
         float v = c < 17 ? (float)src[c * HW + pix] : 0.0f;
@@ -692,6 +692,110 @@ static inline bool launch_v5_stem(const bf16_t *X, const bf16_t *Wt, const float
     if (span <= 3 * 128) { hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 3, 32>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos); return true; }
     if (span <= 4 * 128) { hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 4, 32>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos); return true; }
     return false;
+}
+
+// ---------------------------------------------------------------------------
+// Small-batch 3x3 convolution (a single position or a handful: Player.think on one game, play_cmd / GTP
+// style use).  The slab kernel needs >= 256 tiles of 256 points to fill the chip; one 19x19 board is two.
+// Here a workgroup owns 32 board points x 32 or 64 output channels, so one board already spreads over 48-96
+// workgroups, and its 4 or 8 waves split the reduction axis (tap x 32-channel steps) between them: operands
+// go straight from L2 into registers in MFMA layout (16 B per lane, no LDS staging - there is no reuse
+// inside such a small tile worth staging for), several steps of loads in flight per wave, and the
+// partial accumulators are folded through LDS before the bias / residual / ReLU epilogue.
+// ---------------------------------------------------------------------------
+// NW waves per workgroup = ways the reduction axis is split; NI 16-channel blocks per workgroup; UN steps of loads
+// in flight per wave.  <8, 2, 9>: one or two boards (72 steps / 8 waves = one batch of loads, lowest latency);
+// <4, 4, 3>: up to about 16 boards (fewer, larger workgroups: less operand re-reading).
+template <bool RESID, int NW, int NI, int UN>
+__global__ __launch_bounds__(64 * NW) void k_conv3x3_bf16_small(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
+                                                                      const float *__restrict__ bias, const bf16_t *__restrict__ R,
+                                                                      bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP, int CIN,
+                                                                      int COUT)
+{
+    __shared__ float part[NW][NI * 2][64][4];  // [wave][i*2+j][lane][r]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * (16 * NI), W2 = Wd + 2;
+    const int fr = lane & 15, fq = lane >> 4;
+    // padded position of this lane's point in each of the two 16-point blocks (clamped; stores are masked)
+    int pos[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int m = min(m0 + j * 16 + fr, M - 1);
+        const int b = m / HW, pix = m - b * HW, y = pix / Wd, x = pix - y * Wd;
+        pos[j] = b * PP + (y + 1) * W2 + (x + 1);
+    }
+    const int nchunk = CIN / 32, nsteps = 9 * nchunk;
+    const bf16_t *wrow[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) wrow[i] = Wt + (size_t)(c0 + i * 16 + fr) * 9 * CIN + fq * 8;
+    f32x4 acc[NI][2];
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int h0 = wave; h0 < nsteps; h0 += NW * UN) {
+        bf16x8 wf[UN][NI], xf[UN][2];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int h = min(h0 + NW * u, nsteps - 1);  // past the end: reload the last step, not used below
+            const int tap = h / nchunk, cc = h - tap * nchunk;
+            const int ty = tap / 3, tx = tap - ty * 3;
+            const int koff = tap * CIN + cc * 32;
+            const int xo = ((ty - 1) * W2 + (tx - 1)) * CIN + cc * 32 + fq * 8;
+#pragma unroll
+            for (int i = 0; i < NI; i++) wf[u][i] = *reinterpret_cast<const bf16x8 *>(wrow[i] + koff);
+#pragma unroll
+            for (int j = 0; j < 2; j++) xf[u][j] = *reinterpret_cast<const bf16x8 *>(X + (size_t)pos[j] * CIN + xo);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            if (h0 + NW * u < nsteps) {
+#pragma unroll
+                for (int i = 0; i < NI; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][i], xf[u][j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) *reinterpret_cast<f32x4 *>(&part[wave][i * 2 + j][lane][0]) = acc[i][j];
+    __syncthreads();
+    // the NI * 2 (channel block i, point block j) pairs are finished by the waves in turn:
+    // channels c0 + i*16 + fq*4 .. +3 of point j*16 + fr
+    for (int pr = wave; pr < NI * 2; pr += NW) {
+        const int i = pr >> 1, j = pr & 1;
+        const int ch = c0 + i * 16 + fq * 4;
+        const float4 b4 = *reinterpret_cast<const float4 *>(bias + ch);
+        f32x4 v = *reinterpret_cast<const f32x4 *>(&part[0][pr][lane][0]);
+#pragma unroll
+        for (int w = 1; w < NW; w++) v += *reinterpret_cast<const f32x4 *>(&part[w][pr][lane][0]);
+        const int pj = j ? pos[1] : pos[0];
+        if (m0 + j * 16 + fr < M) {
+            const size_t o = (size_t)pj * COUT + ch;
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+            if (RESID) {
+                const uint2 rr = *reinterpret_cast<const uint2 *>(R + o);
+                r0 = __uint_as_float(rr.x << 16); r1 = __uint_as_float(rr.x & 0xffff0000u);
+                r2 = __uint_as_float(rr.y << 16); r3 = __uint_as_float(rr.y & 0xffff0000u);
+            }
+            uint2 pk;
+            pk.x = pack_bf16(fmaxf(v[0] + b4.x + r0, 0.f), fmaxf(v[1] + b4.y + r1, 0.f));
+            pk.y = pack_bf16(fmaxf(v[2] + b4.z + r2, 0.f), fmaxf(v[3] + b4.w + r3, 0.f));
+            *reinterpret_cast<uint2 *>(Y + o) = pk;
+        }
+    }
+}
+
+template <int NW, int NI, int UN>
+static inline void launch_small(const bf16_t *X, const bf16_t *Wt, const float *bias, const bf16_t *R, bf16_t *Y, int M, int HW, int Wd,
+                                int PP, int cin, int cout, hipStream_t st)
+{
+    dim3 gs((M + 31) / 32, cout / (16 * NI)), bs(64 * NW);
+    if (R) hipLaunchKernelGGL((k_conv3x3_bf16_small<true, NW, NI, UN>), gs, bs, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, cin, cout);
+    else hipLaunchKernelGGL((k_conv3x3_bf16_small<false, NW, NI, UN>), gs, bs, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, cin, cout);
 }
 
 // ---------------------------------------------------------------------------

@@ -16,6 +16,11 @@
 
 #include "az_conv_kernels.h"
 
+// up to this many board points per forward the small-batch convolution is used (16 boards of 19x19)
+#ifndef SMALL_BATCH_POINTS
+#define SMALL_BATCH_POINTS 5776
+#endif
+
 struct Tower {
     int H, W, HW, PP, O, NB, C, dtype, maxB;
     size_t blob_floats;
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(256) void k_head_conv(const T *__restrict__ X, cons
         for (int k = 0; k < EPL; k++) { wreg[0][k] = wh[cl * EPL + k]; wreg[1][k] = wh[C + cl * EPL + k]; wreg[2][k] = wh[2 * C + cl * EPL + k]; }
     }
     const int npass = (HW + 4 * PPW - 1) / (4 * PPW);
-    for (int it = 0; it < npass; it++) {
+    for (int it = blockIdx.y; it < npass; it += gridDim.y) {
         const int pix = (it * 4 + wave) * PPW + sub;
         const bool ok = pix < HW;
         const int pc = ok ? pix : HW - 1;
@@ -344,6 +349,12 @@ void launch_conv<bf16_t>(const Tower *t, const bf16_t *X, const bf16_t *Wt, cons
 {
     const int M = B * t->HW;
     dim3 grid((M + 127) / 128, t->C / 128), block(256);
+    // a few positions only: spread them over many small workgroups instead of a handful of 256-point tiles
+    if (M <= SMALL_BATCH_POINTS && cin % 32 == 0 && t->C % 64 == 0) {
+        if (M <= SMALL_BATCH_POINTS / 8) launch_small<8, 2, 9>(X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C, st);
+        else launch_small<4, 4, 3>(X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C, st);
+        return;
+    }
     if (cin == 256 && t->C == 256) {
         // slab kernel when a 256-pixel tile spans at most 512 padded positions (boards of 8x8 and larger)
         if (launch_v5(X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, st)) return;
@@ -378,7 +389,8 @@ static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float
 {
     const size_t C = t->C;
     T *X0 = (T *)t->X0, *X = (T *)t->X, *Tm = (T *)t->T, *Y = (T *)t->Y;
-    hipLaunchKernelGGL((k_planes_to_nhwc<T>), dim3(B), dim3(256), 0, st, planes, X0, t->H, t->W, rows);
+    const int ysplit = B < 64 ? 8 : 1;  // few boards: several workgroups per board in the memory-bound kernels
+    hipLaunchKernelGGL((k_planes_to_nhwc<T>), dim3(B, ysplit), dim3(256), 0, st, planes, X0, t->H, t->W, rows);
     launch_conv<T>(t, X0, (const T *)t->w_stem, t->b_stem, (const T *)nullptr, X, B, CIN0, st);
     for (int l = 0; l < t->NB; l++) {
         const T *w1 = (const T *)t->w_conv + (size_t)(2 * l) * C * 9 * C;
@@ -395,10 +407,10 @@ static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float
         int lpp = 64;
         while (chunks % lpp) lpp >>= 1;                     // largest power of two <= 64 dividing it
         if (chunks == lpp)
-            hipLaunchKernelGGL((k_head_conv<T, true>), dim3(B), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, t->hp, t->hv, t->HW,
+            hipLaunchKernelGGL((k_head_conv<T, true>), dim3(B, ysplit), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, t->hp, t->hv, t->HW,
                                t->W, t->PP, (int)C, lpp);
         else
-            hipLaunchKernelGGL((k_head_conv<T, false>), dim3(B), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, t->hp, t->hv, t->HW,
+            hipLaunchKernelGGL((k_head_conv<T, false>), dim3(B, ysplit), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, t->hp, t->hv, t->HW,
                                t->W, t->PP, (int)C, lpp);
     }
     hipLaunchKernelGGL(k_head_fc, dim3((B + FCB - 1) / FCB), dim3(384), 0, st, t->hp, t->hv, t->w_pfc, t->b_pfc, t->w_v1, t->b_v1, t->w_v2,

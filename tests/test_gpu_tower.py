@@ -19,13 +19,20 @@ TOL = {"fp32": 1e-5, "bf16": 1e-2}
     ("go", 9, 9, 2, 256, 7),
     ("go", 19, 19, 2, 256, 3),
     ("mnk", 6, 5, 1, 128, 4),
+    # batches past the small-batch kernels: the slab kernel (256 channels) and the generic tile kernel
+    ("go", 19, 19, 1, 256, 20),
+    ("go", 9, 9, 1, 256, 90),
+    ("reversi", 8, 8, 1, 256, 100),
+    ("mnk", 15, 15, 1, 256, 30),
+    ("mnk", 3, 3, 1, 256, 700),
+    ("go", 9, 9, 1, 128, 90),
 ])
 def test_tower_matches_fp32_reference(dtype, game, H, W, NB, C, B):
     from alphazero_amd.engine import Engine
     from alphazero_amd.network.model import fold_to_blob, random_net
     O = H * W + (0 if game == "mnk" else 1)
     net = random_net(H, W, O, NB, C, seed=H * 100 + NB, perturb_bn=True)
-    eng = Engine(game, H, W, 3, n_slots=4, num_blocks=NB, channels=C, tower_dtype=dtype)
+    eng = Engine(game, H, W, 3, n_slots=4 if B < 16 else B, num_blocks=NB, channels=C, tower_dtype=dtype)
     blob = fold_to_blob(net)
     assert blob.size == eng.tower_blob_floats()
     eng.tower_load(blob)
