@@ -32,6 +32,32 @@ def history_arrays(eng, moves, visits, winner, slot=0):
     return state_np, probs_np, result_np
 
 
+def history_arrays_batch(eng, games):
+    """history_arrays for many finished games at once: `games` = [(moves, visits, winner)], at most eng.G of them.
+    All games are replayed in lockstep, one batched feature call and one batched move call per ply."""
+    n = len(games)
+    assert n <= eng.G
+    H, W, O = eng.H, eng.W, eng.O
+    lens = [len(g[0]) for g in games]
+    states = [np.zeros((T, 17, H, W)) for T in lens]
+    eng.reset(list(range(n)))
+    for i in range(max(lens, default=0)):
+        act = [k for k in range(n) if lens[k] > i]
+        planes = eng.features(act, [0] * len(act))
+        for q, k in enumerate(act):
+            states[k][i] = planes[q]
+        status, _ = eng.do_move(act, [int(games[k][0][i]) for k in act])
+        assert np.all(status == 0)
+    out = []
+    for k, (moves, visits, winner) in enumerate(games):
+        T = lens[k]
+        v = np.asarray(visits, np.float64)
+        probs_np = v / v.sum(axis=1, keepdims=True) if T else np.zeros((0, O))
+        result_np = np.array([1.0 if (i % 2 == (winner != 1)) else -1.0 for i in range(T)])
+        out.append((states[k], probs_np, result_np))
+    return out
+
+
 class Game:
     def __init__(self, nn_eval_1, nn_eval_2, game_config, ext_config):
         self.player_1 = player.Player(nn_eval_1, game_config, ext_config['player'])
@@ -85,7 +111,12 @@ class Game:
 
 class BatchedSelfplay:
     """`n_games` concurrent self-play games on one GPU; the role of Selfplay.run +
-    selfplay_wrapper (train/parallel/selfplay.py:71-108) without a process per game."""
+    selfplay_wrapper (train/parallel/selfplay.py:71-108) without a process per game.
+
+    Finished games are turned into get_history() tuples on a second engine (its own HIP stream) by a
+    background thread, so the self-play engine keeps running rounds meanwhile."""
+
+    REPLAY_SLOTS = 64
 
     def __init__(self, nn_eval, game_config, ext_config, n_games, seed=0, device=0):
         kw = game_config_to_engine_kwargs(game_config)
@@ -95,7 +126,7 @@ class BatchedSelfplay:
                           tower_dtype=nn_eval.dtype, device=device, **kw)
         self._nn_eval = nn_eval
         self._version = None
-        self._replay = Engine(n_slots=1, **kw)
+        self._replay = Engine(n_slots=self.REPLAY_SLOTS, device=device, **kw)
         self.n_games = n_games
         self._started = False
 
@@ -104,20 +135,33 @@ class BatchedSelfplay:
             self.eng.tower_load(self._nn_eval._tower_blob)
             self._version = self._nn_eval.version
 
+    def _convert(self, popped):
+        out = []
+        for i in range(0, len(popped), self.REPLAY_SLOTS):
+            out += history_arrays_batch(self._replay, popped[i:i + self.REPLAY_SLOTS])
+        return out
+
     def run(self, num_games, rounds_per_poll=64):
-        """Play until `num_games` games have finished; returns their get_history() tuples."""
+        """Play until `num_games` games have finished; returns their get_history() tuples in finishing order."""
+        from concurrent.futures import ThreadPoolExecutor
         self._sync_weights()
         if not self._started:
             self.eng.selfplay_start()
             self._started = True
-        out = []
-        while len(out) < num_games:
-            self.eng.selfplay_run(rounds_per_poll)
-            _, done = self.eng.selfplay_status()
-            for s in np.flatnonzero(done):
-                tr = self.eng.trajectory_pop(int(s), restart=True)
-                out.append(history_arrays(self._replay, tr["moves"], tr["visits"], tr["winner"]))
-            self._sync_weights()
+        n_popped, pending = 0, []
+        with ThreadPoolExecutor(max_workers=1) as pool:   # one worker: conversions stay in finishing order
+            while n_popped < num_games:
+                self.eng.selfplay_run(rounds_per_poll)    # the C call releases the GIL: the worker converts meanwhile
+                _, done = self.eng.selfplay_status()
+                popped = []
+                for s in np.flatnonzero(done):
+                    tr = self.eng.trajectory_pop(int(s), restart=True)
+                    popped.append((tr["moves"], tr["visits"], tr["winner"]))
+                if popped:
+                    n_popped += len(popped)
+                    pending.append(pool.submit(self._convert, popped))
+                self._sync_weights()
+            out = [h for f in pending for h in f.result()]
         return out[:num_games]
 
 

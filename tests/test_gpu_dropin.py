@@ -255,3 +255,30 @@ def test_dummy_evaluator_search_runs_in_float64_like_the_reference():
     finally:
         _restore(saved)
     assert np.array_equal(st.board, g["final_board"])
+
+
+def test_batched_history_replay_matches_single_game_replay():
+    """history_arrays_batch (lockstep replay of many games) == history_arrays (one game at a time), ragged lengths."""
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.game.gameplay import history_arrays, history_arrays_batch
+    from oracle import oracle as oz
+    rng = np.random.RandomState(4)
+    games = []
+    for g in range(5):
+        st = oz.State("go", 7, 7)
+        moves, visits = [], []
+        for _ in range(rng.randint(0, 25)):
+            legal = np.flatnonzero(st.legal_mask())
+            a = int(rng.choice(legal))
+            v = np.zeros(50, np.int32); v[legal] = rng.randint(1, 9, len(legal))
+            moves.append(a); visits.append(v)
+            if st.do_move(a) != 0 or st.s.is_end:
+                break
+        games.append((np.array(moves, np.int16), np.array(visits, np.int32).reshape(len(moves), 50), int(rng.choice([-1, 0, 1]))))
+    eb = Engine("go", 7, 7, n_slots=8)
+    e1 = Engine("go", 7, 7, n_slots=1)
+    batch = history_arrays_batch(eb, games)
+    for (m, v, w), (s, p, r) in zip(games, batch):
+        s1, p1, r1 = history_arrays(e1, m, v, w)
+        assert np.array_equal(s, s1) and np.array_equal(p, p1) and np.array_equal(r, r1)
+    eb.close(); e1.close()
