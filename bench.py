@@ -80,7 +80,12 @@ def cpu_baseline(game, H, k, num_blocks, channels, sims, budget_s=20.0):
             ref = json.load(f)
     except OSError:
         pass
+    est = None
+    if ref and "reference_over_port_torch_fp32" in ref:
+        # port timing on this host x (reference / port) ratio measured side by side in the build container
+        est = sims_per_s * ref["reference_over_port_torch_fp32"]
     return {
+        "reference_equivalent_sims_per_sec_estimate": est,
         "reference_python_in_build_container": ref,
         "value": sims_per_s / (sims + 1), "unit": "moves/s", "sims_per_sec": sims_per_s, "cores": cores, "kind": "port",
         "sample": "first %d simulations of one %s %dx%d game's first search (%d-block %d-ch fp32 net on CPU, "

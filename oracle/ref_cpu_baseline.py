@@ -83,6 +83,24 @@ def main():
         out[name] = {"sims": sims, "seconds": dt, "sims_per_sec": sims / dt, "moves_per_sec_at_800": sims / dt / 801.0,
                      "processes": 1}
         print(name, out[name])
+    # the C port (oracle/liboracle.so) on the same host under the same two evaluators: its ratio to the reference
+    # converts a port timing taken elsewhere (the GPU box's host) into a reference-equivalent estimate
+    from oracle import oracle as oz
+
+    def port_torch(planes, O_):
+        x = torch.from_numpy(np.ascontiguousarray(planes)).float()[None]
+        p, v = tower_ref.forward(sd, x, args.blocks)
+        return p[0].numpy(), float(v[0])
+
+    for name, ev, n in (("uniform", oz.fn_ptr("oz_uniform_eval"), 20 * args.sims), ("torch_fp32", oz.make_eval(port_torch), args.net_sims)):
+        tree = oz.Tree(O, 8)
+        st = oz.State("go", H, W)
+        t0 = time.perf_counter()
+        evals = tree.search(st, n, True, ev, oz.Rng(seed=1))
+        dt = time.perf_counter() - t0
+        out["port_" + name] = {"sims": int(evals), "seconds": dt, "sims_per_sec": evals / dt}
+        out["reference_over_port_" + name] = out[name]["sims_per_sec"] / (evals / dt)
+        print("port", name, out["port_" + name], "reference/port", out["reference_over_port_" + name])
     path = os.path.join(HERE, "..", "tests", "golden", "cpu_baseline_reference.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
