@@ -132,6 +132,14 @@ def test_selfplay_machine_full_game(name):
     ("reversi", 6, 6, 0, 8, 24, 30, 400, 8),
     ("go", 9, 9, 0, 8, 48, 30, 12, 8),
     ("mnk", 7, 7, 4, 8, 30, 30, 400, 8),
+    # the named configurations at their full simulation counts, a few plies of a few games each
+    ("reversi", 8, 8, 0, 8, 400, 30, 9, 4),
+    ("go", 9, 9, 0, 8, 400, 30, 7, 4),
+    ("mnk", 15, 15, 5, 8, 800, 30, 3, 2),
+    ("go", 19, 19, 0, 8, 800, 30, 5, 4),
+    # whole games to their natural end (two passes / full board), noise running out after ply 30
+    ("go", 9, 9, 0, 8, 60, 30, 400, 3),
+    ("reversi", 8, 8, 0, 8, 60, 30, 400, 3),
 ])
 def test_selfplay_machine_vs_oracle(game, H, W, k, tt, P, db, mt, G):
     """G different seeded games in one engine vs the C oracle's oz_play_game, full trajectories."""
