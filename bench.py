@@ -33,9 +33,10 @@ def measured_traffic(games, board, channels):
             d = json.load(f)
     except OSError:
         return None, None
-    if (d.get("boards"), d.get("board"), d.get("channels")) != (games, board, channels):
+    if (d.get("board"), d.get("channels")) != (board, channels):
         return None, None
-    return d["traffic_bytes_per_launch"], d["source"]
+    # per-launch traffic is proportional to the number of boards (activations in/out; the weights are 0.05 %)
+    return int(d["traffic_bytes_per_launch"] * games / d["boards"]), d["source"] + "; measured at %d boards, scaled to %d" % (d["boards"], games)
 
 
 def cpu_baseline(game, H, k, num_blocks, channels, sims, budget_s=20.0):
@@ -154,7 +155,12 @@ def main():
         # trajectories and activations (about 0.7 MB); larger batches keep the tower's tiles flowing (fewer tails)
         per_game = 2 * (3 * (args.sims + 1) * O * 18 + 8 * (args.sims + 1) * 24) + (402 * O * 4 + 402 * 2) + 3 * 441 * 256 * 2 + 64 * 1024
         free, _ = torch.cuda.mem_get_info(local_rank)
-        args.games = int(max(256, min(4096, (int(0.85 * free) // per_game) // 256 * 256)))
+        gmax = int(max(256, min(4096, int(0.85 * free) // per_game)))
+        # the tower's conv tiles are 256 board points; pick the largest game count whose tiles fill a whole number of
+        # rounds over the CUs (no partly idle last round in each of the 40 conv launches): 3993 games of 19x19 = 22 rounds
+        cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        rounds = (gmax * H * H) // (256 * cus)
+        args.games = (rounds * 256 * cus) // (H * H) if rounds >= 1 else gmax
     eng = Engine(args.game, H, H, args.k, n_slots=args.games, max_playout=args.sims, transform_types=8, dirichlet_before=30,
                  max_turn=400, d_alpha=0.03, d_epsilon=0.25, seed=1000 + rank, record_trajectories=True,
                  num_blocks=args.blocks, channels=args.channels, tower_dtype=args.dtype, device=local_rank)
