@@ -24,7 +24,7 @@ class AzConfig(C.Structure):
         ("tree_edge_cap", C.c_int32), ("tree_block_cap", C.c_int32), ("max_depth", C.c_int32),
         ("rng_replay", C.c_int32), ("seed", C.c_uint64), ("record_trajectories", C.c_int32),
         ("num_blocks", C.c_int32), ("channels", C.c_int32), ("tower_dtype", C.c_int32), ("device", C.c_int32),
-        ("search_f64", C.c_int32),
+        ("tree_full_policy", C.c_int32), ("search_f64", C.c_int32),
     ]
 
 
@@ -48,6 +48,7 @@ class AzCounters(C.Structure):
         ("tower_ms", C.c_double), ("select_ms", C.c_double), ("finish_ms", C.c_double),
         ("tower_calls", C.c_uint64), ("tower_evals", C.c_uint64),
         ("conv_ms", C.c_double), ("conv_launches", C.c_uint64), ("conv_flops_per_launch", C.c_double),
+        ("expansions_skipped", C.c_uint64),
     ]
 
 

@@ -28,7 +28,7 @@ enum { PH_IDLE = 0, PH_NEED_START = 1, PH_IN_SEARCH = 2, PH_SEARCH_DONE = 3, PH_
 #define NOMOVE (-2)
 
 enum {
-    C_STEPS = 0, C_EVALS, C_MOVES, C_GAMES, C_LEVELS, C_CHILDREN, C_EDGES, C_RULEMOVES, C_NLEAVES, C_N = 16
+    C_STEPS = 0, C_EVALS, C_MOVES, C_GAMES, C_LEVELS, C_CHILDREN, C_EDGES, C_RULEMOVES, C_NLEAVES, C_SKIPPED, C_N = 16
 };
 
 struct Geo {
@@ -56,6 +56,7 @@ struct Dev {
     double d_alpha, d_epsilon;
     int EC, BC, MAXD;
     int rng_replay, record, traj_plies;
+    int full_policy;     // 0: a full tree arena is an error; 1: the expansion is skipped and counted
     unsigned long long seed;
     // state
     int8_t *ring;        // [G][8][AZ_CP]

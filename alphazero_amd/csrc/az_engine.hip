@@ -144,6 +144,7 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     D.MAXD = cfg->max_depth > 0 ? cfg->max_depth : 1024;
     D.rng_replay = cfg->rng_replay; D.seed = cfg->seed;
     D.record = cfg->record_trajectories;
+    D.full_policy = cfg->tree_full_policy ? 1 : 0;
     D.traj_plies = cfg->record_trajectories ? cfg->max_turn + 2 : 1;
 
     bool ok = hipStreamCreate(&h->stream) == hipSuccess;
@@ -853,7 +854,7 @@ extern "C" int az_counters_get(az_engine *h, az_counters *out)
     HIPCHK(hipMemcpy(c, h->D.ctr, sizeof c, hipMemcpyDeviceToHost));
     out->steps = h->steps; out->evals = c[C_EVALS]; out->moves = c[C_MOVES]; out->games_finished = c[C_GAMES];
     out->levels = c[C_LEVELS]; out->children_scanned = c[C_CHILDREN]; out->edges_created = c[C_EDGES];
-    out->rule_moves = c[C_RULEMOVES];
+    out->rule_moves = c[C_RULEMOVES]; out->expansions_skipped = c[C_SKIPPED];
     out->tower_ms = h->tower_ms; out->select_ms = h->select_ms; out->finish_ms = h->finish_ms;
     out->tower_calls = h->tower_calls; out->tower_evals = h->tower_evals;
     out->conv_ms = 0; out->conv_launches = 0; out->conv_flops_per_launch = 0;

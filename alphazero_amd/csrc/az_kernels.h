@@ -253,9 +253,12 @@ __global__ __launch_bounds__(64) void k_finish(Dev D)
             }
             n += __popcll(__ballot(legal));
         }
-        if (bi >= D.BC || start + n > D.EC) { if (lane == 0) D.err[g] = -4; return; }
+        // a full arena is an error, or (tree_full_policy 1, never at a root) the node simply stays a leaf for this
+        // playout: its value is backed up as usual and the event is counted
+        const int full = (bi >= D.BC || start + n > D.EC);
+        if (full && (D.full_policy == 0 || root_expand)) { if (lane == 0) D.err[g] = -4; return; }
         int off = 0;
-        for (int i0 = 0; i0 < G.O; i0 += AZ_WAVE) {
+        for (int i0 = 0; i0 < G.O && !full; i0 += AZ_WAVE) {
             int i = i0 + lane;
             int legal = 0, a = 0;
             if (i < G.O) {
@@ -271,7 +274,8 @@ __global__ __launch_bounds__(64) void k_finish(Dev D)
             off += __popcll(bal);
         }
         if (lane == 0) {
-            if (n > 0) {
+            if (full) atomicAdd(&D.ctr[C_SKIPPED], 1ULL);
+            if (n > 0 && !full) {
                 D.bStart[bb + bi] = start; D.bCount[bb + bi] = n;
                 D.bOwner[bb + bi] = node; D.bParent[bb + bi] = D.leaf_block[g];
                 D.nBlocks[t] = bi + 1; D.nEdges[t] = start + n;

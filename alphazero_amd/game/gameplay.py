@@ -113,6 +113,10 @@ class BatchedSelfplay:
     """`n_games` concurrent self-play games on one GPU; the role of Selfplay.run +
     selfplay_wrapper (train/parallel/selfplay.py:71-108) without a process per game.
 
+    The engine runs with tree_full_policy 1: should a search tree ever outgrow its arena (long forced lines with
+    almost all visits kept across re-roots), that playout's node stays a leaf instead of stopping every game;
+    `eng.counters()["expansions_skipped"]` tells how often that happened (0 = the run is exact).
+
     Finished games are turned into get_history() tuples on a second engine (its own HIP stream) by a
     background thread, so the self-play engine keeps running rounds meanwhile."""
 
@@ -123,7 +127,7 @@ class BatchedSelfplay:
         self.eng = Engine(n_slots=n_games, max_playout=ext_config['player']['max_playout'],
                           dirichlet_before=ext_config['dirichlet_before'], max_turn=ext_config['max_turn'],
                           record_trajectories=True, seed=seed, num_blocks=nn_eval.num_blocks, channels=nn_eval.channels,
-                          tower_dtype=nn_eval.dtype, device=device, **kw)
+                          tower_dtype=nn_eval.dtype, device=device, tree_full_policy=1, **kw)
         self._nn_eval = nn_eval
         self._version = None
         self._replay = Engine(n_slots=self.REPLAY_SLOTS, device=device, **kw)
@@ -203,7 +207,7 @@ class BatchedMatch:
             self.eng = Engine(n_slots=self.n_parallel, max_playout=gp['player']['max_playout'],
                               dirichlet_before=gp['dirichlet_before'], max_turn=gp['max_turn'], record_trajectories=True,
                               seed=self.seed, num_blocks=ev.num_blocks, channels=ev.channels, tower_dtype=ev.dtype,
-                              device=self.device, **game_config_to_engine_kwargs(self.game_config))
+                              device=self.device, tree_full_policy=1, **game_config_to_engine_kwargs(self.game_config))
         return self.eng
 
     def run(self, rounds_per_poll=64):

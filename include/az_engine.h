@@ -68,6 +68,9 @@ typedef struct az_config {
     int32_t channels;          /* 256 in the reference (model.py:47,55-56) */
     int32_t tower_dtype;       /* AZ_TOWER_FP32 / AZ_TOWER_BF16 */
     int32_t device;            /* HIP device ordinal */
+    int32_t tree_full_policy;  /* 0: a full tree arena stops the run with AZ_ERR_TREE_FULL (the reference has no limit, so
+                                  nothing else is exact); 1: the node stays a leaf for that playout, its value is still
+                                  backed up, and az_counters.expansions_skipped counts the event (production runs) */
     int32_t search_f64;        /* 0: N/W/P arithmetic in float32 (a float32 evaluator: the network, nn_eval_parallel.py:75-92);
                                   1: in float64 (an evaluator returning Python floats / float64: evaluator/dummy_eval.py:26-28).
                                   With 1 the tower cannot feed the search; use the *_f64 entry points */
@@ -99,6 +102,7 @@ typedef struct az_counters {
     double conv_ms;            /* HIP-event time of the residual-tower 3x3 conv launches (az_tower_profile on) */
     uint64_t conv_launches;
     double conv_flops_per_launch; /* 2 * n_slots * H*W * 9 * C^2 */
+    uint64_t expansions_skipped;  /* tree_full_policy 1: expansions dropped because an arena was full */
 } az_counters;
 
 /* ---- lifetime ------------------------------------------------------- */

@@ -180,6 +180,23 @@ def test_tree_arena_overflow_is_reported():
     eng.close()
 
 
+def test_tree_arena_overflow_policy_skip_keeps_searching():
+    """tree_full_policy 1: the playout whose expansion does not fit backs its value up without expanding; the search
+    finishes with one visit per playout and the skipped expansions are counted."""
+    from alphazero_amd.engine import Engine
+    eng = Engine("go", 5, 5, n_slots=1, max_playout=50, transform_types=0, tree_edge_cap=60, tree_block_cap=4,
+                 tree_full_policy=1)
+    eng.search_begin([0], [0], [0])
+    assert _run_search(eng) == 51
+    a, n, w, p, rootN = eng.root_stats(0, 0)
+    assert rootN == 51 and n.sum() == 50 and len(a) == 26
+    c = eng.counters()
+    assert c["expansions_skipped"] > 0 and c["edges_created"] <= 60
+    edges, blocks = eng.tree_size(0, 0)
+    assert edges <= 60 and blocks <= 4
+    eng.close()
+
+
 def test_reroot_keeps_subtree_and_compacts():
     """update_with_move: the kept child's statistics survive, the arena shrinks, a move that is
     not a child gives a fresh root (search/mcts.py:336-346)."""
