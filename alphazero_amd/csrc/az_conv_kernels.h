@@ -401,9 +401,14 @@ __device__ __forceinline__ void conv_epilogue_direct(const int *rowoff, f32x4 (&
 // LDS-DMA stays in flight across it).  With -DSTAMP (development harness only) one workgroup records
 // the shader clock after every barrier.
 // ---------------------------------------------------------------------------
+#ifdef ABL_NOBAR
+#define AZ_S_BARRIER() do {} while (0)
+#else
+#define AZ_S_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 #ifdef STAMP
 __device__ unsigned long long g_stamps[2][512];
-#define PP_BAR() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); \
+#define PP_BAR() do { asm volatile("" ::: "memory"); AZ_S_BARRIER(); asm volatile("" ::: "memory"); \
     if (blockIdx.x == 300 && (threadIdx.x & 255) == 0 && stamp_i < 512) g_stamps[threadIdx.x >> 8][stamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PP_BAR() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
@@ -594,6 +599,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
     issue_slab(0); issue_w(0, 0); issue_w(0, 1); issue_w(0, 2);
     wait_vmcnt<4>();
     PP_BAR();
+#ifdef STAMP
+    if (blockIdx.x == 300 && threadIdx.x == 0) { g_stamps[0][500] = __builtin_amdgcn_s_memrealtime(); g_stamps[0][502] = __builtin_amdgcn_s_memtime(); }
+#endif
     if (wr == 0) {
         for (int cc = 0; cc < NCC; cc++) {
             asm volatile("" : "+s"(opaque0));
@@ -626,6 +634,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
     }
 #undef SB
 #undef PP_MID
+#ifdef STAMP
+    if (blockIdx.x == 300 && threadIdx.x == 0) { g_stamps[0][501] = __builtin_amdgcn_s_memrealtime(); g_stamps[0][503] = __builtin_amdgcn_s_memtime(); }
+#endif
 #ifndef MFMA_BUILTIN
     // the compiler does not know that the asm statements above are MFMAs, so it cannot insert the wait
     // states an MFMA result needs before a vector ALU read: cover the longest case by hand

@@ -109,8 +109,13 @@ int main(int argc, char **argv)
         static unsigned long long st[2][512];
         CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof st));
         printf("interval durations (cycles), group0 / group1 stamps after each barrier:\n");
-        for (int i = 1; i < 60; i++) printf("%3d: g0 %6lld  g1 %6lld   (g1-g0 skew %lld)\n", i, (long long)(st[0][i] - st[0][i - 1]), (long long)(st[1][i] - st[1][i - 1]), (long long)(st[1][i] - st[0][i]));
+        if (getenv("VERBOSE")) for (int i = 1; i < 60; i++) printf("%3d: g0 %6lld  g1 %6lld   (g1-g0 skew %lld)\n", i, (long long)(st[0][i] - st[0][i - 1]), (long long)(st[1][i] - st[1][i - 1]), (long long)(st[1][i] - st[0][i]));
         printf("total g0 %lld cycles over 146 barriers\n", (long long)(st[0][145] - st[0][0]));
+        {
+            double rt = (double)(st[0][501] - st[0][500]) * 10.0;  // 100 MHz ticks -> ns
+            double cyc = (double)(st[0][503] - st[0][502]);
+            printf("K loop of one workgroup: %.0f shader cycles in %.0f ns -> %.3f GHz, %.1f cycles per 32-MFMA interval\n", cyc, rt, cyc / rt, cyc / 145.0);
+        }
     }
 #endif
     hipEvent_t e0, e1;
