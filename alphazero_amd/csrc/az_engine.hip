@@ -10,6 +10,7 @@
 #include <vector>
 
 static std::string g_create_error;
+#define AZ_EVQ 8
 
 #define HIPCHK(call)                                                                          \
     do {                                                                                      \
@@ -38,7 +39,11 @@ struct az_engine {
     // replay streams
     std::vector<void *> rng_bufs;  // 3 per slot
     // timing
-    hipEvent_t ev[4];
+    // a ring of event quads (round start / select done / tower done / round done): rounds are launched up to
+    // AZ_EVQ ahead of the host, their phase times folded in when their quad is reused or the call ends
+    hipEvent_t ev[AZ_EVQ][4];
+    int ev_head = 0, ev_pending = 0;
+    bool conv_profile = false;
     double tower_ms = 0, select_ms = 0, finish_ms = 0;
     uint64_t tower_calls = 0, tower_evals = 0, steps = 0;
     bool started = false;
@@ -99,7 +104,8 @@ extern "C" void az_engine_destroy(az_engine *h)
     if (h->tower2) tower_destroy(h->tower2);
     for (void *p : h->allocs) hipFree(p);
     for (void *p : h->rng_bufs) if (p) hipFree(p);
-    for (int i = 0; i < 4; i++) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+    for (int q = 0; q < AZ_EVQ; q++)
+        for (int i = 0; i < 4; i++) if (h->ev[q][i]) hipEventDestroy(h->ev[q][i]);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -121,7 +127,8 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_error = "no HIP device"; return nullptr; }
     if (hipSetDevice(cfg->device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return nullptr; }
     az_engine *h = new az_engine();
-    for (int i = 0; i < 4; i++) h->ev[i] = nullptr;
+    for (int q = 0; q < AZ_EVQ; q++)
+        for (int i = 0; i < 4; i++) h->ev[q][i] = nullptr;
     h->cfg = *cfg;
     Dev &D = h->D;
     memset(&D, 0, sizeof(D));
@@ -148,7 +155,8 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     D.traj_plies = cfg->record_trajectories ? cfg->max_turn + 2 : 1;
 
     bool ok = hipStreamCreate(&h->stream) == hipSuccess;
-    for (int i = 0; i < 4 && ok; i++) ok = hipEventCreate(&h->ev[i]) == hipSuccess;
+    for (int q = 0; q < AZ_EVQ && ok; q++)
+        for (int i = 0; i < 4 && ok; i++) ok = hipEventCreate(&h->ev[q][i]) == hipSuccess;
 #define A(field, T, n) ok = ok && ((D.field = dalloc<T>(h, (size_t)(n))) != nullptr)
     A(ring, int8_t, (size_t)G * 8 * AZ_CP);
     A(sc, int32_t, (size_t)G * S_N);
@@ -615,30 +623,47 @@ static void launch_tail(az_engine *h)
     else hipLaunchKernelGGL(k_reroot<float>, dim3(2 * h->D.G), dim3(64), 0, h->stream, h->D);
 }
 
+// waits for the oldest queued round and folds its phase times into the counters
+static int drain_round(az_engine *h)
+{
+    hipEvent_t *ev = h->ev[h->ev_head];
+    HIPCHK(hipEventSynchronize(ev[3]));
+    float a = 0, b = 0, c = 0;
+    hipEventElapsedTime(&a, ev[0], ev[1]);
+    hipEventElapsedTime(&b, ev[1], ev[2]);
+    hipEventElapsedTime(&c, ev[2], ev[3]);
+    h->select_ms += a; h->tower_ms += b; h->finish_ms += c;
+    if (h->conv_profile) tower_collect_profile(h->tower);
+    h->steps++;
+    h->ev_head = (h->ev_head + 1) % AZ_EVQ;
+    h->ev_pending--;
+    return AZ_OK;
+}
+
 extern "C" int az_selfplay_run(az_engine *h, int32_t n_rounds)
 {
     if (!h || n_rounds < 0) return AZ_ERR_ARG;
     if (!h->started) return set_err(h, AZ_ERR_STATE, "az_selfplay_start has not been called");
     if (!h->tower || !tower_ready(h->tower)) return set_err(h, AZ_ERR_NO_WEIGHTS, "no tower weights loaded");
     HIPCHK(hipSetDevice(h->cfg.device));
+    // per-launch conv timing reuses one set of events per forward and the two-network split reads counts back every
+    // round, so those modes keep the host in step with the device; otherwise rounds are queued AZ_EVQ deep
+    const int depth = (h->conv_profile || h->two_nets) ? 1 : AZ_EVQ;
     for (int r = 0; r < n_rounds; r++) {
-        HIPCHK(hipEventRecord(h->ev[0], h->stream));
+        if (h->ev_pending >= depth) { int rc = drain_round(h); if (rc) return rc; }
+        hipEvent_t *ev = h->ev[(h->ev_head + h->ev_pending) % AZ_EVQ];
+        HIPCHK(hipEventRecord(ev[0], h->stream));
         int rc = launch_select(h);
         if (rc) return rc;
-        HIPCHK(hipEventRecord(h->ev[1], h->stream));
+        HIPCHK(hipEventRecord(ev[1], h->stream));
         if ((rc = evaluate(h, nullptr, nullptr))) return rc;
-        HIPCHK(hipEventRecord(h->ev[2], h->stream));
+        HIPCHK(hipEventRecord(ev[2], h->stream));
         launch_tail(h);
-        HIPCHK(hipEventRecord(h->ev[3], h->stream));
-        HIPCHK(hipEventSynchronize(h->ev[3]));
-        float a = 0, b = 0, c = 0;
-        hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
-        hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
-        hipEventElapsedTime(&c, h->ev[2], h->ev[3]);
-        h->select_ms += a; h->tower_ms += b; h->finish_ms += c;
-        tower_collect_profile(h->tower);
-        h->steps++;
+        HIPCHK(hipEventRecord(ev[3], h->stream));
+        h->ev_pending++;
+        if (depth == 1) { if ((rc = drain_round(h))) return rc; }
     }
+    while (h->ev_pending > 0) { int rc = drain_round(h); if (rc) return rc; }
     HIPCHK(hipGetLastError());
     return check_slot_errors(h);
 }
@@ -838,6 +863,7 @@ extern "C" int az_tower_profile(az_engine *h, int32_t on)
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
     tower_set_profile(h->tower, on != 0);
+    h->conv_profile = on != 0;
     return AZ_OK;
 }
 
