@@ -38,12 +38,56 @@ import AlphaZero.processing.state_converter as sc  # noqa: E402
 import AlphaZero.search.mcts as mcts  # noqa: E402
 
 
+def ttt(args):
+    """Whole tic-tac-toe games through the reference's Game class (gameplay.py:38-71), 100 sims per move, a 2-block
+    256-channel fp32 PyTorch-CPU network: the reference's own CPU-runnable configuration."""
+    import torch
+    import AlphaZero.env.mnk as mnk
+    import AlphaZero.game.gameplay as gameplay
+    from alphazero_amd.network.model import random_net
+    from oracle import tower_ref
+    gameplay.printlog = lambda *a, **k: None
+    with open(os.path.join(REF, "AlphaZero", "config", "mnk.yaml")) as f:
+        cfg = yaml.load(f)
+    cfg.update(board_height=3, board_width=3, k=3, flat_move_output=9, transform_types=0)
+    mnk.game_config.update(board_height=3, board_width=3, k=3)
+    s2t, t2a = sc.StateTensorConverter(cfg), sc.TensorActionConverter(cfg)
+    net = random_net(3, 3, 9, 2, 256, seed=0)
+    sd = net.state_dict()
+
+    class Ev:
+        def eval(self, state):
+            x = torch.from_numpy(np.ascontiguousarray(s2t.state_to_tensor(state))).float()
+            p, v = tower_ref.forward(sd, x, 2)
+            return t2a.tensor_to_action(p[0].numpy()), np.float32(v[0])
+    ext = {"player": {"max_playout": 100}, "dirichlet_before": 30, "log_iter": 10 ** 9, "max_turn": 400}
+    np.random.seed(0)
+    t0 = time.perf_counter()
+    games = plies = 0
+    while time.perf_counter() - t0 < 20.0:
+        g = gameplay.Game(Ev(), Ev(), cfg, ext)
+        g.start()
+        plies += len(g.get_history()[1])
+        games += 1
+    dt = time.perf_counter() - t0
+    out = {"workload": "mnk 3x3x3 self-play through gameplay.Game, 100 sims/move, 2-block 256-ch fp32 net on CPU",
+           "games": games, "plies": plies, "seconds": dt, "moves_per_sec": plies / dt, "sims_per_sec": plies * 101 / dt,
+           "torch_threads": torch.get_num_threads(), "processes": 1}
+    print(out)
+    path = os.path.join(HERE, "..", "tests", "golden", "cpu_baseline_reference_ttt.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sims", type=int, default=200)
     ap.add_argument("--net-sims", type=int, default=40)
     ap.add_argument("--blocks", type=int, default=20)
+    ap.add_argument("--ttt", action="store_true", help="the tic-tac-toe configuration (mnk 3x3x3, 100 sims, 2 blocks) instead of Go 19x19")
     args = ap.parse_args()
+    if args.ttt:
+        return ttt(args)
     import torch
     from alphazero_amd.network.model import random_net
     from oracle import tower_ref
