@@ -95,6 +95,7 @@ SIGNATURES = {
     "az_tower_load_weights_net": (_I, [_P, _I, _P, C.c_size_t]),
     "az_match_assign": (_I, [_P, _P, _I, _P]),
     "az_tower_forward": (_I, [_P, _P, _I, _P, _P]),
+    "az_tower_forward_dev": (_I, [_P, _P, _I, _P, _P]),
     "az_tower_flops_per_eval": (C.c_double, [_P]),
     "az_tower_profile": (_I, [_P, _I]),
     "az_counters_get": (_I, [_P, C.POINTER(AzCounters)]),

@@ -857,6 +857,24 @@ extern "C" int az_tower_forward(az_engine *h, const int8_t *planes, int32_t B, f
     return AZ_OK;
 }
 
+extern "C" int az_tower_forward_dev(az_engine *h, const int8_t *planes_dev, int32_t B, float *out_p_dev, float *out_v_dev)
+{
+    if (!h || !planes_dev || !out_p_dev || !out_v_dev || B < 1) return AZ_ERR_ARG;
+    if (!h->tower || !tower_ready(h->tower)) return set_err(h, AZ_ERR_NO_WEIGHTS, "no tower weights loaded");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int G = h->D.G, O = h->D.geo.O, NC = h->D.geo.NC;
+    std::string terr;
+    for (int b0 = 0; b0 < B; b0 += G) {  // the activation buffers hold n_slots boards
+        const int nb = std::min(G, B - b0);
+        if (tower_forward(h->tower, planes_dev + (size_t)b0 * 17 * NC, nb, out_p_dev + (size_t)b0 * O, out_v_dev + b0, h->stream, terr) != 0) {
+            h->error = "tower: " + terr;
+            return AZ_ERR_HIP;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return AZ_OK;
+}
+
 extern "C" int az_tower_profile(az_engine *h, int32_t on)
 {
     if (!h || !h->tower) return AZ_ERR_ARG;

@@ -242,6 +242,18 @@ class Engine:
         self._ck(self._L.az_tower_forward(self._h, x.ctypes.data, B, p.ctypes.data, v.ctypes.data))
         return p, v
 
+    def tower_forward_torch(self, planes):
+        """planes: int8 CUDA tensor (B,17,H,W) on this engine's GPU -> (priors (B,O), values (B,)) float32 CUDA tensors;
+        nothing crosses PCIe."""
+        import torch
+        assert planes.is_cuda and planes.dtype == torch.int8 and planes.is_contiguous()
+        B = planes.shape[0]
+        p = torch.empty((B, self.O), dtype=torch.float32, device=planes.device)
+        v = torch.empty((B,), dtype=torch.float32, device=planes.device)
+        torch.cuda.current_stream(planes.device).synchronize()   # the engine runs on its own stream
+        self._ck(self._L.az_tower_forward_dev(self._h, planes.data_ptr(), B, p.data_ptr(), v.data_ptr()))
+        return p, v
+
     def tower_profile(self, on=True):
         self._ck(self._L.az_tower_profile(self._h, int(on)))
 

@@ -203,6 +203,9 @@ int az_tower_load_weights_net(az_engine *h, int32_t net, const float *blob, size
 int az_match_assign(az_engine *h, const int32_t *slots, int32_t n, const int32_t *net_of_first);
 /* x int8 (B,17,H,W) host; out_p (B,O), out_v (B) float32 host */
 int az_tower_forward(az_engine *h, const int8_t *planes, int32_t B, float *out_p, float *out_v);
+/* the same with all three arrays already in this GPU's memory (e.g. torch.Tensor.data_ptr()); returns after the
+ * engine's stream has finished, so the outputs can be read from any stream */
+int az_tower_forward_dev(az_engine *h, const int8_t *planes_dev, int32_t B, float *out_p_dev, float *out_v_dev);
 double az_tower_flops_per_eval(az_engine *h);
 /* on=1: bracket every residual-tower convolution launch of az_selfplay_run with HIP events on the
  * launch stream and accumulate conv_ms / conv_launches in az_counters (measurement only) */

@@ -81,3 +81,17 @@ def test_selfplay_with_tower_runs_and_counts():
     assert np.all(done2 == 0) and np.all(plies2 == 0)
     eng.selfplay_run(30)
     eng.close()
+
+
+def test_tower_forward_on_device_tensors():
+    """az_tower_forward_dev: device pointers in, device pointers out, same numbers as the host-buffer entry point."""
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.network.model import fold_to_blob, random_net
+    H, NB, C = 9, 2, 256
+    eng = Engine("go", H, H, n_slots=32, num_blocks=NB, channels=C, tower_dtype="bf16")
+    eng.tower_load(fold_to_blob(random_net(H, H, H * H + 1, NB, C, seed=2, perturb_bn=True)))
+    x = (np.random.RandomState(1).rand(70, 17, H, H) < 0.3).astype(np.int8)   # 70 > n_slots: chunked
+    p, v = eng.tower_forward(x)
+    pt, vt = eng.tower_forward_torch(torch.from_numpy(x).cuda())
+    assert pt.is_cuda and np.array_equal(pt.cpu().numpy(), p) and np.array_equal(vt.cpu().numpy(), v)
+    eng.close()
