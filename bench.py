@@ -137,12 +137,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    # rehearsal on a box with fewer GPUs than ranks: AZ_BENCH_DEVICE pins every rank to one card and
+    # AZ_BENCH_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
+    if "AZ_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["AZ_BENCH_DEVICE"])
+    backend = os.environ.get("AZ_BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:  # under torchrun the RCCL path is taken even with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from alphazero_amd.engine import Engine
     from alphazero_amd.network.model import fold_to_blob, random_net
