@@ -436,6 +436,20 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {}
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 #endif
 
+// Workgroups are handed to the 8 XCDs round-robin (workgroup i -> XCD i % 8), each XCD with its own L2.  Tiles that
+// are neighbours in memory share their halo rows, so workgroup i takes tile (i % 8) * ceil-share + i / 8: every XCD
+// walks one contiguous range of tiles and the halo rows of a tile are already in that XCD's L2 (bijective for any
+// workgroup count).  Placement is only a matter of speed, never of correctness.
+__device__ __forceinline__ int xcd_tile(int wg, int nwg)
+{
+#ifdef NO_XCD_REMAP
+    return wg;
+#else
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+#endif
+}
+
 template <bool RESID, int NSP, int CIN = 256>
 __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
                                                                 const float *__restrict__ bias, const bf16_t *__restrict__ R,
@@ -451,7 +465,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
     int *srow = reinterpret_cast<int *>(smem + 147456 + 1024);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
-    const int m0 = blockIdx.x * 256, W2 = Wd + 2;
+    const int m0 = xcd_tile(blockIdx.x, gridDim.x) * 256, W2 = Wd + 2;
     if (tid < 256) {
         int m = min(m0 + tid, M - 1);
         int b = m / HW, pix = m - b * HW, y = pix / Wd, x = pix - y * Wd;
