@@ -14,15 +14,15 @@ def _blobs(H, W, O, NB, C):
             fold_to_blob(random_net(H, W, O, NB, C, seed=2, perturb_bn=True)))
 
 
-@pytest.mark.parametrize("H,C,dtype", [(5, 128, "fp32"), (9, 256, "bf16")])
-def test_two_network_routing_is_exact(H, C, dtype):
+@pytest.mark.parametrize("H,C,dtype,G,P,max_turn", [(5, 128, "fp32", 6, 10, 12), (9, 256, "bf16", 6, 10, 12),
+                                                   (5, 128, "bf16", 1500, 3, 5)])   # > 1024 slots: several partition passes
+def test_two_network_routing_is_exact(H, C, dtype, G, P, max_turn):
     from alphazero_amd.engine import Engine
-    G, P, NB, O = 6, 10, 1, H * H + 1
-    max_turn = 12
+    NB, O = 1, H * H + 1
     kw = dict(n_slots=G, max_playout=P, transform_types=8, dirichlet_before=4, max_turn=max_turn, record_trajectories=True,
               seed=11, num_blocks=NB, channels=C, tower_dtype=dtype)
     blob_a, blob_b = _blobs(H, H, O, NB, C)
-    first = np.array([0, 1, 0, 1, 1, 0], np.int32)
+    first = np.resize(np.array([0, 1, 0, 1, 1, 0, 1], np.int32), G)
     rounds = (max_turn + 3) * (P + 1)
 
     fast = Engine("go", H, H, **kw)
