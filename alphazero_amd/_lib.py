@@ -24,6 +24,7 @@ class AzConfig(C.Structure):
         ("tree_edge_cap", C.c_int32), ("tree_block_cap", C.c_int32), ("max_depth", C.c_int32),
         ("rng_replay", C.c_int32), ("seed", C.c_uint64), ("record_trajectories", C.c_int32),
         ("num_blocks", C.c_int32), ("channels", C.c_int32), ("tower_dtype", C.c_int32), ("device", C.c_int32),
+        ("leaves_per_round", C.c_int32), ("virtual_loss", C.c_double),
         ("tree_full_policy", C.c_int32), ("search_f64", C.c_int32),
     ]
 

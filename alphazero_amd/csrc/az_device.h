@@ -56,14 +56,19 @@ struct Dev {
     double d_alpha, d_epsilon;
     int EC, BC, MAXD;
     int rng_replay, record, traj_plies;
+    // Several leaves of one tree per round (not in the reference, which has one playout in flight; changes visit
+    // counts): the round's select and finish kernels run K times, sub-round j keeping its leaf in row j*G + g of every
+    // per-leaf array below, and every edge on a path in flight carries a virtual loss vloss on W until its value arrives.
+    int K;
+    double vloss;
     int full_policy;     // 0: a full tree arena is an error; 1: the expansion is skipped and counted
     unsigned long long seed;
     // state
     int8_t *ring;        // [G][8][AZ_CP]
     int32_t *sc;         // [G][S_N]
     // machine
-    int32_t *phase, *side, *dflag, *pdone, *automode, *ply, *err;
-    // leaf of the current round
+    int32_t *phase, *side, *dflag, *pdone, *issued, *automode, *ply, *err;  // issued: playouts started in this search
+    // leaves of the current round: rows [K*G]
     int32_t *leaf_valid, *leaf_node, *leaf_block, *leaf_player, *leaf_end, *leaf_winner, *leaf_tid, *leaf_root, *path_len;
     int32_t *path_node;  // [G][MAXD]
     int8_t *path_player; // [G][MAXD]

@@ -152,6 +152,8 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     D.rng_replay = cfg->rng_replay; D.seed = cfg->seed;
     D.record = cfg->record_trajectories;
     D.full_policy = cfg->tree_full_policy ? 1 : 0;
+    D.K = cfg->leaves_per_round > 1 ? cfg->leaves_per_round : 1;
+    D.vloss = cfg->virtual_loss;
     D.traj_plies = cfg->record_trajectories ? cfg->max_turn + 2 : 1;
 
     bool ok = hipStreamCreate(&h->stream) == hipSuccess;
@@ -162,18 +164,20 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     A(sc, int32_t, (size_t)G * S_N);
     A(phase, int32_t, G); A(side, int32_t, G); A(dflag, int32_t, G); A(pdone, int32_t, G);
     A(automode, int32_t, G); A(ply, int32_t, G); A(err, int32_t, G);
-    A(leaf_valid, int32_t, G); A(leaf_node, int32_t, G); A(leaf_block, int32_t, G); A(leaf_player, int32_t, G);
-    A(leaf_end, int32_t, G); A(leaf_winner, int32_t, G); A(leaf_tid, int32_t, G); A(leaf_root, int32_t, G);
-    A(path_len, int32_t, G);
-    A(path_node, int32_t, (size_t)G * D.MAXD);
-    A(path_player, int8_t, (size_t)G * D.MAXD);
-    A(leaf_mask, uint8_t, (size_t)G * AZ_OP);
-    A(planes, int8_t, (size_t)G * 17 * NC + 64);
+    const size_t LG = (size_t)D.K * G;  // leaf rows per round
+    A(issued, int32_t, G);
+    A(leaf_valid, int32_t, LG); A(leaf_node, int32_t, LG); A(leaf_block, int32_t, LG); A(leaf_player, int32_t, LG);
+    A(leaf_end, int32_t, LG); A(leaf_winner, int32_t, LG); A(leaf_tid, int32_t, LG); A(leaf_root, int32_t, LG);
+    A(path_len, int32_t, LG);
+    A(path_node, int32_t, LG * D.MAXD);
+    A(path_player, int8_t, LG * D.MAXD);
+    A(leaf_mask, uint8_t, LG * AZ_OP);
+    A(planes, int8_t, LG * 17 * NC + 64);
     D.f64 = cfg->search_f64 ? 1 : 0;
     const size_t rs = D.f64 ? 8 : 4;  // bytes of one search statistic
 #define AR(field, n) ok = ok && ((D.field = dalloc<char>(h, (size_t)(n) * rs)) != nullptr)
-    AR(priors, (size_t)G * O);
-    AR(values, G);
+    AR(priors, LG * O);
+    AR(values, LG);
     const size_t T = 2 * (size_t)G;
     A(rootN, int32_t, T); AR(rootW, T); AR(rootP, T); A(rootBlock, int32_t, T);
     A(nBlocks, int32_t, T); A(nEdges, int32_t, T); A(pending, int32_t, T);
@@ -206,7 +210,7 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     h->rng_bufs.assign((size_t)3 * G, nullptr);
     if (cfg->num_blocks > 0) {
         std::string terr;
-        h->tower = tower_create(H, W, O, cfg->num_blocks, cfg->channels > 0 ? cfg->channels : 256, cfg->tower_dtype, G, terr);
+        h->tower = tower_create(H, W, O, cfg->num_blocks, cfg->channels > 0 ? cfg->channels : 256, cfg->tower_dtype, D.K * G, terr);
         if (!h->tower) { g_create_error = "tower: " + terr; az_engine_destroy(h); return nullptr; }
     }
     hipLaunchKernelGGL(k_reset, dim3(G), dim3(64), 0, h->stream, D, (const int32_t *)nullptr, G, 0);
@@ -409,8 +413,10 @@ extern "C" int az_search_begin(az_engine *h, const int32_t *slots, int32_t n, co
 static int launch_select(az_engine *h)
 {
     HIPCHK(hipMemsetAsync(h->D.ctr + C_NLEAVES, 0, sizeof(unsigned long long), h->stream));
-    if (h->D.f64) hipLaunchKernelGGL(k_select<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
-    else hipLaunchKernelGGL(k_select<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
+    for (int sub = 0; sub < h->D.K; sub++) {
+        if (h->D.f64) hipLaunchKernelGGL(k_select<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
+        else hipLaunchKernelGGL(k_select<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
+    }
     HIPCHK(hipGetLastError());
     return AZ_OK;
 }
@@ -432,7 +438,7 @@ extern "C" int az_leaf_batch(az_engine *h, int8_t *planes, uint8_t *valid)
 {
     if (!h) return AZ_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device));
-    const int G = h->D.G;
+    const int G = h->D.K * h->D.G;  // leaf rows: [leaves_per_round][n_slots]
     if (planes)
         HIPCHK(hipMemcpyAsync(planes, h->D.planes, (size_t)G * 17 * h->D.geo.NC, hipMemcpyDeviceToHost, h->stream));
     std::vector<int32_t> v(G);
@@ -445,20 +451,21 @@ extern "C" int az_leaf_batch(az_engine *h, int8_t *planes, uint8_t *valid)
 // priors / values: host arrays of the engine's statistic type (f64 says which the caller passed), or NULL = run the tower
 static int evaluate(az_engine *h, const void *priors, const void *values, int f64 = 0)
 {
-    const int G = h->D.G, O = h->D.geo.O;
+    const int G = h->D.G, O = h->D.geo.O, LG = h->D.K * h->D.G;
     if ((priors == nullptr) != (values == nullptr)) return set_err(h, AZ_ERR_ARG, "priors and values must both be given or both NULL");
     if (priors) {
         if (f64 != h->D.f64)
             return set_err(h, AZ_ERR_ARG, h->D.f64 ? "engine searches in float64: use the _f64 entry point" : "engine searches in float32: use the float entry point");
         const size_t rs = h->D.f64 ? 8 : 4;
-        HIPCHK(hipMemcpyAsync(h->D.priors, priors, rs * (size_t)G * O, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->D.values, values, rs * G, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->D.priors, priors, rs * (size_t)LG * O, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->D.values, values, rs * LG, hipMemcpyHostToDevice, h->stream));
         return AZ_OK;
     }
     if (h->D.f64) return set_err(h, AZ_ERR_ARG, "a float64 search takes injected priors only: the tower's outputs are float32");
     if (!h->tower || !tower_ready(h->tower)) return set_err(h, AZ_ERR_NO_WEIGHTS, "no tower weights loaded and no priors injected");
     std::string terr;
     if (h->two_nets) {
+        if (h->D.K > 1) return set_err(h, AZ_ERR_ARG, "two-network matches run one leaf per tree per round (leaves_per_round = 1)");
         if (!h->tower2 || !tower_ready(h->tower2)) return set_err(h, AZ_ERR_NO_WEIGHTS, "two-network match: network 1 has no weights");
         hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, h->stream, h->D, (const int32_t *)h->net_first, h->net_rows, h->net_cnt);
         int32_t cnt[2] = {0, 0};
@@ -476,12 +483,12 @@ static int evaluate(az_engine *h, const void *priors, const void *values, int f6
         }
         return AZ_OK;
     }
-    if (tower_forward(h->tower, h->D.planes, G, (float *)h->D.priors, (float *)h->D.values, h->stream, terr) != 0) {
+    if (tower_forward(h->tower, h->D.planes, LG, (float *)h->D.priors, (float *)h->D.values, h->stream, terr) != 0) {
         h->error = "tower: " + terr;
         return AZ_ERR_HIP;
     }
     h->tower_calls++;
-    h->tower_evals += G;
+    h->tower_evals += LG;
     return AZ_OK;
 }
 
@@ -500,8 +507,10 @@ static int step_finish(az_engine *h, const void *priors, const void *values, int
     HIPCHK(hipSetDevice(h->cfg.device));
     int rc = evaluate(h, priors, values, f64);
     if (rc) return rc;
-    if (h->D.f64) hipLaunchKernelGGL(k_finish<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
-    else hipLaunchKernelGGL(k_finish<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
+    for (int sub = 0; sub < h->D.K; sub++) {
+        if (h->D.f64) hipLaunchKernelGGL(k_finish<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
+        else hipLaunchKernelGGL(k_finish<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
+    }
     HIPCHK(hipGetLastError());
     h->steps++;
     return check_slot_errors(h);
@@ -616,8 +625,10 @@ extern "C" int az_selfplay_start(az_engine *h)
 
 static void launch_tail(az_engine *h)
 {
-    if (h->D.f64) hipLaunchKernelGGL(k_finish<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
-    else hipLaunchKernelGGL(k_finish<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
+    for (int sub = 0; sub < h->D.K; sub++) {
+        if (h->D.f64) hipLaunchKernelGGL(k_finish<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
+        else hipLaunchKernelGGL(k_finish<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
+    }
     hipLaunchKernelGGL(k_move, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
     if (h->D.f64) hipLaunchKernelGGL(k_reroot<double>, dim3(2 * h->D.G), dim3(64), 0, h->stream, h->D);
     else hipLaunchKernelGGL(k_reroot<float>, dim3(2 * h->D.G), dim3(64), 0, h->stream, h->D);

@@ -99,18 +99,21 @@ __device__ void apply_noise(const Dev &D, int g, int t)
 // ---------------------------------------------------------------------------
 
 template <typename R>
-__global__ __launch_bounds__(64) void k_select(Dev D)
+__global__ __launch_bounds__(64) void k_select(Dev D, int sub)
 {
     __shared__ WLds L;
-    const R *const eW = static_cast<const R *>(D.eW);
+    R *const eW = static_cast<R *>(D.eW);
     const R *const eP = static_cast<const R *>(D.eP);
     const int g = blockIdx.x;
+    const int li = sub * D.G + g;  // row of this sub-round's leaf
     const int lane = lane_id();
     const Geo G = D.geo;
     int phase = D.phase[g];
-    if (lane == 0) D.leaf_valid[g] = 0;
+    if (lane == 0) D.leaf_valid[li] = 0;
     if (phase != PH_NEED_START && phase != PH_IN_SEARCH) return;
     if (D.err[g] != 0) return;
+    // sub-rounds after the first only add playouts to a search that is under way and has budget left
+    if (sub > 0 && (phase != PH_IN_SEARCH || D.issued[g] >= D.max_playout)) return;
     const int side = D.side[g];
     const int t = 2 * g + side;
     const size_t tb = (size_t)t * D.EC, bb = (size_t)t * D.BC;
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(64) void k_select(Dev D)
         } else {
             if (D.dflag[g]) apply_noise<R>(D, g, t);
             phase = PH_IN_SEARCH;
-            if (lane == 0) { D.phase[g] = PH_IN_SEARCH; D.pdone[g] = 0; }
+            if (lane == 0) { D.phase[g] = PH_IN_SEARCH; D.pdone[g] = 0; D.issued[g] = 0; }
             if (D.max_playout == 0) {
                 if (lane == 0) { D.phase[g] = PH_SEARCH_DONE; D.rootN[t] = rootN; }
                 return;
@@ -170,42 +173,48 @@ __global__ __launch_bounds__(64) void k_select(Dev D)
             int e = start + bi;
             if (depth >= D.MAXD) { if (lane == 0) D.err[g] = -6; return; }
             if (lane == 0) {
-                D.path_node[(size_t)g * D.MAXD + depth] = node;
-                D.path_player[(size_t)g * D.MAXD + depth] = (int8_t)s.cur;
+                D.path_node[(size_t)li * D.MAXD + depth] = node;
+                D.path_player[(size_t)li * D.MAXD + depth] = (int8_t)s.cur;
             }
             depth++;
             int a = D.eAct[tb + e];
             dev_do_move(G, L, s, a);
             int N = D.eN[tb + e] + 1;  // child.visit()
             WSYNC();
-            if (lane == 0) D.eN[tb + e] = N;
+            if (lane == 0) {
+                D.eN[tb + e] = N;
+                if (D.K > 1) eW[tb + e] -= (R)D.vloss;  // virtual loss, taken back by k_finish
+            }
             node = e; node_block = blk;
             parentN = N;
             blk = D.eChild[tb + e];
         }
     }
-    if (lane == 0) D.rootN[t] = rootN;
+    if (lane == 0) {
+        D.rootN[t] = rootN;
+        if (!root_expand) D.issued[g] += 1;
+    }
 
     // leaf: transform id, legality on the un-transformed state, evaluator input
     int tid = D.transform_on ? rng_tid(D, g) : 0;
     int nlegal = dev_legal_mask(G, L, s);
-    uint8_t *gm = D.leaf_mask + (size_t)g * AZ_OP;
+    uint8_t *gm = D.leaf_mask + (size_t)li * AZ_OP;
     for (int i = lane; i < AZ_OP / 4; i += AZ_WAVE)
         reinterpret_cast<int *>(gm)[i] = reinterpret_cast<int *>(L.mask)[i];
     int terminal = (nlegal == 0) || s.is_end;
     int win = 0;
     if (terminal && !root_expand) win = dev_winner(G, L, s);
-    dev_features(G, L, s, tid, D.planes + (size_t)g * 17 * G.NC);
+    dev_features(G, L, s, tid, D.planes + (size_t)li * 17 * G.NC);
     if (lane == 0) {
-        D.leaf_valid[g] = 1;
-        D.leaf_node[g] = node;
-        D.leaf_block[g] = node_block;
-        D.leaf_player[g] = s.cur;
-        D.leaf_end[g] = terminal;
-        D.leaf_winner[g] = win;
-        D.leaf_tid[g] = tid;
-        D.leaf_root[g] = root_expand;
-        D.path_len[g] = depth;
+        D.leaf_valid[li] = 1;
+        D.leaf_node[li] = node;
+        D.leaf_block[li] = node_block;
+        D.leaf_player[li] = s.cur;
+        D.leaf_end[li] = terminal;
+        D.leaf_winner[li] = win;
+        D.leaf_tid[li] = tid;
+        D.leaf_root[li] = root_expand;
+        D.path_len[li] = depth;
         atomicAdd(&D.ctr[C_LEVELS], levels);
         atomicAdd(&D.ctr[C_CHILDREN], scanned);
         atomicAdd(&D.ctr[C_RULEMOVES], (unsigned long long)depth);
@@ -219,28 +228,37 @@ __global__ __launch_bounds__(64) void k_select(Dev D)
 // ---------------------------------------------------------------------------
 
 template <typename R>
-__global__ __launch_bounds__(64) void k_finish(Dev D)
+__global__ __launch_bounds__(64) void k_finish(Dev D, int sub)
 {
     R *const eW = static_cast<R *>(D.eW);
     R *const eP = static_cast<R *>(D.eP);
     R *const rootW = static_cast<R *>(D.rootW);
     const int g = blockIdx.x;
+    const int li = sub * D.G + g;
     const int lane = lane_id();
     const Geo G = D.geo;
-    if (!D.leaf_valid[g] || D.err[g] != 0) return;
+    if (!D.leaf_valid[li] || D.err[g] != 0) return;
     const int side = D.side[g];
     const int t = 2 * g + side;
     const size_t tb = (size_t)t * D.EC, bb = (size_t)t * D.BC;
-    const int root_expand = D.leaf_root[g];
-    const int node = D.leaf_node[g];
-    const int player = D.leaf_player[g];
-    const int tid = D.leaf_tid[g];
-    R v = static_cast<const R *>(D.values)[g];
-    const uint8_t *mask = D.leaf_mask + (size_t)g * AZ_OP;
-    const R *pri = static_cast<const R *>(D.priors) + (size_t)g * G.O;
+    const int root_expand = D.leaf_root[li];
+    const int node = D.leaf_node[li];
+    const int player = D.leaf_player[li];
+    const int tid = D.leaf_tid[li];
+    R v = static_cast<const R *>(D.values)[li];
+    const uint8_t *mask = D.leaf_mask + (size_t)li * AZ_OP;
+    const R *pri = static_cast<const R *>(D.priors) + (size_t)li * G.O;
+    const R vl = D.K > 1 ? (R)D.vloss : (R)0.0;
     WSYNC();
-    const int expandable = root_expand ? 1 : !D.leaf_end[g];
-    if (expandable) {
+    // with several leaves in flight an earlier sub-round of this round may already have expanded the node
+    const int has_children = D.K > 1 && (node == NODE_ROOT ? D.rootBlock[t] >= 0 : D.eChild[tb + node] >= 0);
+    const int expandable = root_expand ? 1 : !D.leaf_end[li];
+    if (expandable && has_children) {
+        if (lane == 0) {
+            R add = (R)(-player) * v;
+            if (node == NODE_ROOT) rootW[t] += add; else eW[tb + node] += add + vl;
+        }
+    } else if (expandable) {
         int bi = D.nBlocks[t], start = D.nEdges[t];
         // count legal children first so that a full arena is detected before writing
         int n = 0;
@@ -277,37 +295,37 @@ __global__ __launch_bounds__(64) void k_finish(Dev D)
             if (full) atomicAdd(&D.ctr[C_SKIPPED], 1ULL);
             if (n > 0 && !full) {
                 D.bStart[bb + bi] = start; D.bCount[bb + bi] = n;
-                D.bOwner[bb + bi] = node; D.bParent[bb + bi] = D.leaf_block[g];
+                D.bOwner[bb + bi] = node; D.bParent[bb + bi] = D.leaf_block[li];
                 D.nBlocks[t] = bi + 1; D.nEdges[t] = start + n;
                 if (node == NODE_ROOT) D.rootBlock[t] = bi; else D.eChild[tb + node] = bi;
                 atomicAdd(&D.ctr[C_EDGES], (unsigned long long)n);
             }
             // node.update(value): raw value at the root, -player*value below it
             R add = root_expand ? v : (R)(-player) * v;
-            if (node == NODE_ROOT) rootW[t] += add; else eW[tb + node] += add;
+            if (node == NODE_ROOT) rootW[t] += add; else eW[tb + node] += add + vl;
         }
     } else {
-        v = (R)D.leaf_winner[g];  // value = state.get_winner()
+        v = (R)D.leaf_winner[li];  // value = state.get_winner()
         if (lane == 0) {
             R add = (R)(-player) * v;
-            if (node == NODE_ROOT) rootW[t] += add; else eW[tb + node] += add;
+            if (node == NODE_ROOT) rootW[t] += add; else eW[tb + node] += add + vl;
         }
     }
     WSYNC();
     if (root_expand) {
         if (D.dflag[g]) apply_noise<R>(D, g, t);
         if (lane == 0) {
-            D.pdone[g] = 0;
+            D.pdone[g] = 0; D.issued[g] = 0;
             D.phase[g] = D.max_playout == 0 ? PH_SEARCH_DONE : PH_IN_SEARCH;
         }
         return;
     }
     // ancestors: node.update(-current_player * simres_value)
-    int plen = D.path_len[g];
+    int plen = D.path_len[li];
     for (int d = lane; d < plen; d += AZ_WAVE) {
-        int nd = D.path_node[(size_t)g * D.MAXD + d];
-        R add = (R)(-(int)D.path_player[(size_t)g * D.MAXD + d]) * v;
-        if (nd == NODE_ROOT) rootW[t] += add; else eW[tb + nd] += add;
+        int nd = D.path_node[(size_t)li * D.MAXD + d];
+        R add = (R)(-(int)D.path_player[(size_t)li * D.MAXD + d]) * v;
+        if (nd == NODE_ROOT) rootW[t] += add; else eW[tb + nd] += add + vl;
     }
     if (lane == 0) {
         int pd = D.pdone[g] + 1;
@@ -567,7 +585,7 @@ __global__ __launch_bounds__(64) void k_reset(Dev D, const int32_t *slots, int n
     store_scalars(D, g, s);
     if (lane_id() == 0) {
         D.phase[g] = automode ? PH_NEED_START : PH_IDLE;
-        D.side[g] = 0; D.dflag[g] = automode ? (0 <= D.dirichlet_before) : 0; D.pdone[g] = 0;
+        D.side[g] = 0; D.dflag[g] = automode ? (0 <= D.dirichlet_before) : 0; D.pdone[g] = 0; D.issued[g] = 0;
         D.automode[g] = automode; D.ply[g] = 0; D.err[g] = 0; D.leaf_valid[g] = 0; D.tr_winner[g] = 0;
         for (int k = 0; k < 2; k++) {
             int t = 2 * g + k;
@@ -677,7 +695,7 @@ __global__ void k_begin(Dev D, const int32_t *slots, int n, const int32_t *sides
     int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
     int g = slots[q];
-    D.phase[g] = PH_NEED_START; D.side[g] = sides[q]; D.dflag[g] = dflags[q]; D.pdone[g] = 0; D.automode[g] = 0;
+    D.phase[g] = PH_NEED_START; D.side[g] = sides[q]; D.dflag[g] = dflags[q]; D.pdone[g] = 0; D.issued[g] = 0; D.automode[g] = 0;
 }
 
 __global__ void k_set_pending(Dev D, const int32_t *slots, int n, const int32_t *moves, int side_sel)

@@ -35,13 +35,14 @@ class Engine:
     def __init__(self, game, board_height, board_width, k=0, n_slots=1, max_playout=0, transform_types=0,
                  dirichlet_before=30, max_turn=400, d_alpha=0.03, d_epsilon=0.25, tree_edge_cap=0, tree_block_cap=0,
                  max_depth=0, rng_replay=False, seed=0, record_trajectories=False, num_blocks=0, channels=256,
-                 tower_dtype="bf16", device=0, search_f64=False, tree_full_policy=0):
+                 tower_dtype="bf16", device=0, search_f64=False, tree_full_policy=0, leaves_per_round=1,
+                 virtual_loss=1.0):
         self._L = _lib.lib()
         cfg = AzConfig(GAME_IDS[game] if isinstance(game, str) else int(game), board_height, board_width, k, n_slots,
                        max_playout, transform_types, dirichlet_before, max_turn, d_alpha, d_epsilon, tree_edge_cap,
                        tree_block_cap, max_depth, int(rng_replay), seed, int(record_trajectories), num_blocks, channels,
                        {"fp32": 0, "bf16": 1}[tower_dtype] if isinstance(tower_dtype, str) else int(tower_dtype), device,
-                       int(tree_full_policy), int(bool(search_f64)))
+                       int(leaves_per_round), float(virtual_loss), int(tree_full_policy), int(bool(search_f64)))
         self.cfg = cfg
         # dtype of W / P / priors / values: float64 reproduces a search fed by a float64 evaluator (dummy_eval.py:26-28)
         self.real = np.float64 if search_f64 else np.float32
@@ -53,6 +54,7 @@ class Engine:
         self.NC = board_height * board_width
         self.O = self.NC + (0 if cfg.game == 2 else 1)
         self.G = n_slots
+        self.K = max(1, int(leaves_per_round))   # leaf rows per round = K * G, row j * G + slot
 
     def close(self):
         if getattr(self, "_h", None):
@@ -132,8 +134,8 @@ class Engine:
         return n.value
 
     def leaf_batch(self):
-        planes = np.zeros((self.G, NPLANES, self.H, self.W), np.int8)
-        valid = np.zeros(self.G, np.uint8)
+        planes = np.zeros((self.K * self.G, NPLANES, self.H, self.W), np.int8)
+        valid = np.zeros(self.K * self.G, np.uint8)
         self._ck(self._L.az_leaf_batch(self._h, planes.ctypes.data, valid.ctypes.data))
         return planes, valid
 
@@ -143,7 +145,7 @@ class Engine:
             return
         p = np.ascontiguousarray(priors, self.real)
         v = np.ascontiguousarray(values, self.real)
-        assert p.shape == (self.G, self.O) and v.shape == (self.G,)
+        assert p.shape == (self.K * self.G, self.O) and v.shape == (self.K * self.G,)
         fn = self._L.az_search_step_finish_f64 if self.real is np.float64 else self._L.az_search_step_finish
         self._ck(fn(self._h, p.ctypes.data, v.ctypes.data))
 
@@ -190,7 +192,7 @@ class Engine:
             return
         p = np.ascontiguousarray(priors, self.real)
         v = np.ascontiguousarray(values, self.real)
-        assert p.shape == (self.G, self.O) and v.shape == (self.G,)
+        assert p.shape == (self.K * self.G, self.O) and v.shape == (self.K * self.G,)
         fn = self._L.az_selfplay_finish_f64 if self.real is np.float64 else self._L.az_selfplay_finish
         self._ck(fn(self._h, p.ctypes.data, v.ctypes.data))
 

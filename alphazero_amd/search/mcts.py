@@ -62,7 +62,9 @@ class _RootView(object):
 
 
 class MCTSearch(object):
-    def __init__(self, evaluator, game_config, max_playout=1600):
+    def __init__(self, evaluator, game_config, max_playout=1600, leaves_per_round=1):
+        """leaves_per_round > 1 (device evaluators only) searches several leaves of the tree per round under a virtual
+        loss: more simulations per second for a single game, but no longer the reference's visit counts."""
         self._evaluator = evaluator
         self._max_playout = max_playout
         self.d_alpha = game_config['d_alpha']
@@ -78,7 +80,12 @@ class MCTSearch(object):
         tower_kw = {}
         if self._tower is not None:
             tower_kw = dict(num_blocks=self._tower.num_blocks, channels=self._tower.channels, tower_dtype=self._tower.dtype)
-        self._eng_kw = dict(n_slots=1, max_playout=max_playout, rng_replay=True, **kw)
+        if leaves_per_round > 1 and self._tower is None:
+            raise ValueError("leaves_per_round > 1 needs a device evaluator (NNEvaluator)")
+        # replayed draws follow the reference's sequential order, which several leaves in flight do not have
+        self._eng_kw = dict(n_slots=1, max_playout=max_playout, rng_replay=leaves_per_round <= 1,
+                            leaves_per_round=leaves_per_round, **kw)
+        self._multi = leaves_per_round > 1
         self._eng = Engine(**self._eng_kw, **tower_kw)
         self._loaded_version = None
         # Arithmetic of N/W/P follows the evaluator's output type, as NumPy's promotion makes it in the reference:
@@ -103,13 +110,15 @@ class MCTSearch(object):
         root_is_leaf = len(n_children) == 0
         # draws in the reference's order: transform id for the root, noise, one id per playout
         n_tids = (self._max_playout + (1 if root_is_leaf else 0)) if self.enable_transform else 0
-        tids = [int(randint(self._transform_types)) for _ in range(1 if (root_is_leaf and self.enable_transform) else 0)]
-        etas = []
-        if dirichlet:
+        tids, etas = [], []
+        if not self._multi:
+            tids = [int(randint(self._transform_types)) for _ in range(1 if (root_is_leaf and self.enable_transform) else 0)]
+        if dirichlet and not self._multi:
             n = int(state.legal_mask().sum()) if root_is_leaf else len(n_children)
             etas = list(random_variate_dirichlet(self.d_alpha, n))
-        tids += [int(randint(self._transform_types)) for _ in range(n_tids - len(tids))]
-        eng.rng_inject(0, tids, etas, [])
+        if not self._multi:
+            tids += [int(randint(self._transform_types)) for _ in range(n_tids - len(tids))]
+            eng.rng_inject(0, tids, etas, [])
         eng.search_begin([0], [0], [int(bool(dirichlet))])
         if self._tower is not None:
             if self._loaded_version != self._tower.version:

@@ -68,6 +68,11 @@ typedef struct az_config {
     int32_t channels;          /* 256 in the reference (model.py:47,55-56) */
     int32_t tower_dtype;       /* AZ_TOWER_FP32 / AZ_TOWER_BF16 */
     int32_t device;            /* HIP device ordinal */
+    int32_t leaves_per_round;  /* 0/1: one playout in flight per tree, as the reference (search/mcts.py:295-296) - the only
+                                  setting held to the reference's visit counts.  K > 1: K leaves of each tree per round
+                                  (single-game / play use: K times the evaluator batch); per-leaf arrays then have
+                                  K * n_slots rows, row j * n_slots + slot for the j-th leaf of a slot */
+    double virtual_loss;       /* K > 1: subtracted from W of every edge on a path in flight, given back when its value arrives */
     int32_t tree_full_policy;  /* 0: a full tree arena stops the run with AZ_ERR_TREE_FULL (the reference has no limit, so
                                   nothing else is exact); 1: the node stays a leaf for that playout, its value is still
                                   backed up, and az_counters.expansions_skipped counts the event (production runs) */

@@ -217,3 +217,53 @@ def test_reroot_keeps_subtree_and_compacts():
     eng.advance_tree(0, 0, 25 if 25 not in a2 else int(a2[0]))
     eng.advance_tree(0, 0, 0)  # whatever it was, walk on: unknown children reset the tree
     eng.close()
+
+
+@pytest.mark.parametrize("K,vloss", [(4, 1.0), (8, 0.5), (16, 1.0)])
+def test_several_leaves_per_round_keep_the_tree_consistent(K, vloss):
+    """leaves_per_round > 1 (virtual loss; not the reference's schedule): every playout is still counted once, the
+    budget is met exactly, no virtual loss is left behind, and fewer rounds are needed."""
+    from alphazero_amd.engine import Engine
+    P, H = 203, 9
+    eng = Engine("go", H, H, n_slots=2, max_playout=P, transform_types=8, leaves_per_round=K, virtual_loss=vloss, seed=5)
+    assert eng.K == K
+    eng.search_begin([0, 1], [0, 0], [1, 0])
+    rounds = 0
+    while eng.step_select() > 0:
+        planes, valid = eng.leaf_batch()
+        assert planes.shape[0] == K * 2
+        pri, v = fake_eval_planes(planes, eng.O)          # values in [-0.5, 0.5)
+        eng.step_finish(pri, v)
+        rounds += 1
+    assert rounds <= 1 + (P + K - 1) // K + 1 and rounds < P
+    for slot in (0, 1):
+        a, n, w, p, rootN = eng.root_stats(slot, 0)
+        assert rootN == P + 1 and n.sum() == P and len(a) == H * H + 1
+        assert np.all(np.abs(w) <= 0.5 * n + 1e-4)      # a forgotten virtual loss would leave |W| > N / 2
+        best = int(np.argmax(n))
+        eng.do_move([slot], [int(a[best])])
+        eng.advance_tree(slot, 0, int(a[best]))
+        a2, n2, w2, p2, rootN2 = eng.root_stats(slot, 0)
+        assert rootN2 == n[best] and n2.sum() == n[best] - 1
+        assert np.all(np.abs(w2) <= 0.5 * n2 + 1e-4)
+    c = eng.counters()
+    assert c["evals"] == 2 * (P + 1)
+    eng.close()
+
+
+def test_selfplay_with_several_leaves_per_round():
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.network.model import fold_to_blob, random_net
+    G, P, K = 4, 30, 8
+    eng = Engine("mnk", 3, 3, 3, n_slots=G, max_playout=P, num_blocks=1, channels=128, tower_dtype="bf16",
+                 record_trajectories=True, seed=7, leaves_per_round=K)
+    eng.tower_load(fold_to_blob(random_net(3, 3, 9, 1, 128, seed=3)))
+    eng.selfplay_start()
+    eng.selfplay_run(9 * (2 + (P + K - 1) // K) + 5)
+    plies, done = eng.selfplay_status()
+    assert np.all(done == 1) and np.all(plies >= 5) and np.all(plies <= 9)
+    for s in range(G):
+        tr = eng.trajectory_pop(s)
+        assert np.all(tr["visits"].sum(axis=1) >= P) and tr["winner"] in (-1, 0, 1)
+        assert np.all(tr["visits"][0:2].sum(axis=1) == P)   # fresh roots: exactly the budget
+    eng.close()

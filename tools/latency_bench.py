@@ -29,6 +29,23 @@ for B in (1, 2, 4, 8, 16, 17, 32, 64):
     print("tower forward B=%3d: %7.3f ms  (%8.1f evals/s)" % (B, dt * 1e3, B / dt), flush=True)
 eng.close()
 
+for K in (1, 4, 8, 16, 32):
+    e = Engine("go", H, H, n_slots=1, max_playout=800, transform_types=8, num_blocks=NB, channels=256, tower_dtype="bf16", seed=3,
+               leaves_per_round=K)
+    e.tower_load(blob)
+    e.search_begin([0], [0], [1])
+    t0 = time.perf_counter()
+    sims = 0
+    while True:
+        n = e.step_select()
+        if n == 0:
+            break
+        e.step_finish()
+        sims += n
+    dt = time.perf_counter() - t0
+    print("single game search, %2d leaves per round: %d simulations in %.3f s = %.0f sims/s" % (K, sims, dt, sims / dt), flush=True)
+    e.close()
+
 one = Engine("go", H, H, n_slots=1, max_playout=400, transform_types=8, num_blocks=NB, channels=256, tower_dtype="bf16", seed=3)
 one.tower_load(blob)
 one.search_begin([0], [0], [1])
