@@ -1,0 +1,27 @@
+"""Host-side arithmetic of bench.py (no GPU): counters -> HBM figures, PMC traffic scaling."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+
+
+def test_hbm_kernels_bytes_and_rates():
+    c = {"evals": 1000, "children_scanned": 900000, "levels": 2500, "edges_created": 300000,
+         "select_ms": 2.0, "finish_ms": 1.0}
+    sel, fin = bench.hbm_kernels(c, 361, 362, steps=10)
+    assert sel["kernel"] == "k_select" and sel["bound"] == "hbm" and sel["unit"] == "GB/s"
+    sel_bytes = 1000 * (8 * 384 + 17 * 361 + 362) + 12 * 900000 + 8 * 2500
+    assert abs(sel["bytes_per_sim"] - sel_bytes / 1000) < 1e-9
+    assert abs(sel["achieved"] - sel_bytes / 2.0e-3 / 1e9) < 1e-6 and abs(sel["frac"] - sel["achieved"] / 8000.0) < 1e-12
+    fin_bytes = 1000 * 5 * 362 + 18 * 300000 + 8 * 2500
+    assert abs(fin["achieved"] - fin_bytes / 1.0e-3 / 1e9) < 1e-6 and abs(fin["ms_per_step"] - 0.1) < 1e-12
+
+
+def test_measured_traffic_scales_with_boards():
+    t, src = bench.measured_traffic(3993, 19, 256)
+    t2, _ = bench.measured_traffic(7986, 19, 256)
+    assert t > 1e9 and abs(t2 - 2 * t) <= 2 and "FETCH_SIZE" in src
+    assert bench.measured_traffic(1024, 9, 256) == (None, None)      # other board size: no counters taken
