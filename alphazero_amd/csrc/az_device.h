@@ -49,6 +49,7 @@ struct __align__(16) WLds {
     double cum[AZ_OP];
 };
 
+#define AZ_CTR_BUCKETS 256
 struct Dev {
     Geo geo;
     int G;
@@ -93,7 +94,8 @@ struct Dev {
     int16_t *tr_moves;   // [G][traj_plies]
     int32_t *tr_visits;  // [G][traj_plies][O]
     int32_t *tr_winner;  // [G]
-    // counters
+    // counters: AZ_CTR_BUCKETS rows of C_N (a workgroup adds into row blockIdx.x % AZ_CTR_BUCKETS, so thousands of
+    // workgroups do not queue on one address), then AZ_CTR_BUCKETS words for the round's leaf count; the host sums
     unsigned long long *ctr;
 };
 

@@ -192,7 +192,7 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     A(tr_moves, int16_t, (size_t)G * D.traj_plies);
     A(tr_visits, int32_t, (size_t)G * D.traj_plies * O);
     A(tr_winner, int32_t, G);
-    A(ctr, unsigned long long, C_N);
+    A(ctr, unsigned long long, (size_t)AZ_CTR_BUCKETS * (C_N + 1));
 #undef A
 #undef AR
     const size_t stn = std::max(G, 64);
@@ -412,7 +412,7 @@ extern "C" int az_search_begin(az_engine *h, const int32_t *slots, int32_t n, co
 
 static int launch_select(az_engine *h)
 {
-    HIPCHK(hipMemsetAsync(h->D.ctr + C_NLEAVES, 0, sizeof(unsigned long long), h->stream));
+    HIPCHK(hipMemsetAsync(h->D.ctr + (size_t)AZ_CTR_BUCKETS * C_N, 0, sizeof(unsigned long long) * AZ_CTR_BUCKETS, h->stream));
     for (int sub = 0; sub < h->D.K; sub++) {
         if (h->D.f64) hipLaunchKernelGGL(k_select<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
         else hipLaunchKernelGGL(k_select<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
@@ -428,8 +428,10 @@ extern "C" int az_search_step_select(az_engine *h, int32_t *n_leaves)
     int rc = launch_select(h);
     if (rc) return rc;
     unsigned long long nl = 0;
-    HIPCHK(hipMemcpyAsync(&nl, h->D.ctr + C_NLEAVES, sizeof nl, hipMemcpyDeviceToHost, h->stream));
+    unsigned long long nlb[AZ_CTR_BUCKETS];
+    HIPCHK(hipMemcpyAsync(nlb, h->D.ctr + (size_t)AZ_CTR_BUCKETS * C_N, sizeof nlb, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    for (int b = 0; b < AZ_CTR_BUCKETS; b++) nl += nlb[b];
     if (n_leaves) *n_leaves = (int32_t)nl;
     return check_slot_errors(h);
 }
@@ -906,7 +908,13 @@ extern "C" int az_counters_get(az_engine *h, az_counters *out)
     HIPCHK(hipSetDevice(h->cfg.device));
     unsigned long long c[C_N];
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(c, h->D.ctr, sizeof c, hipMemcpyDeviceToHost));
+    {
+        std::vector<unsigned long long> all((size_t)AZ_CTR_BUCKETS * C_N);
+        HIPCHK(hipMemcpy(all.data(), h->D.ctr, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (int i = 0; i < C_N; i++) c[i] = 0;
+        for (int b = 0; b < AZ_CTR_BUCKETS; b++)
+            for (int i = 0; i < C_N; i++) c[i] += all[(size_t)b * C_N + i];
+    }
     out->steps = h->steps; out->evals = c[C_EVALS]; out->moves = c[C_MOVES]; out->games_finished = c[C_GAMES];
     out->levels = c[C_LEVELS]; out->children_scanned = c[C_CHILDREN]; out->edges_created = c[C_EDGES];
     out->rule_moves = c[C_RULEMOVES]; out->expansions_skipped = c[C_SKIPPED];
@@ -927,7 +935,7 @@ extern "C" int az_counters_reset(az_engine *h)
     if (!h) return AZ_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemset(h->D.ctr, 0, sizeof(unsigned long long) * C_N));
+    HIPCHK(hipMemset(h->D.ctr, 0, sizeof(unsigned long long) * AZ_CTR_BUCKETS * (C_N + 1)));
     h->tower_ms = h->select_ms = h->finish_ms = 0;
     h->tower_calls = h->tower_evals = h->steps = 0;
     if (h->tower) { double a; unsigned long long b; tower_profile_read(h->tower, &a, &b, true); }

@@ -215,11 +215,11 @@ __global__ __launch_bounds__(64) void k_select(Dev D, int sub)
         D.leaf_tid[li] = tid;
         D.leaf_root[li] = root_expand;
         D.path_len[li] = depth;
-        atomicAdd(&D.ctr[C_LEVELS], levels);
-        atomicAdd(&D.ctr[C_CHILDREN], scanned);
-        atomicAdd(&D.ctr[C_RULEMOVES], (unsigned long long)depth);
-        atomicAdd(&D.ctr[C_NLEAVES], 1ULL);
-        atomicAdd(&D.ctr[C_EVALS], 1ULL);
+        atomicAdd(&D.ctr[(size_t)(blockIdx.x & (AZ_CTR_BUCKETS - 1)) * C_N + C_LEVELS], levels);
+        atomicAdd(&D.ctr[(size_t)(blockIdx.x & (AZ_CTR_BUCKETS - 1)) * C_N + C_CHILDREN], scanned);
+        atomicAdd(&D.ctr[(size_t)(blockIdx.x & (AZ_CTR_BUCKETS - 1)) * C_N + C_RULEMOVES], (unsigned long long)depth);
+        atomicAdd(&D.ctr[(size_t)AZ_CTR_BUCKETS * C_N + (blockIdx.x & (AZ_CTR_BUCKETS - 1))], 1ULL);
+        atomicAdd(&D.ctr[(size_t)(blockIdx.x & (AZ_CTR_BUCKETS - 1)) * C_N + C_EVALS], 1ULL);
     }
 }
 
@@ -292,13 +292,13 @@ __global__ __launch_bounds__(64) void k_finish(Dev D, int sub)
             off += __popcll(bal);
         }
         if (lane == 0) {
-            if (full) atomicAdd(&D.ctr[C_SKIPPED], 1ULL);
+            if (full) atomicAdd(&D.ctr[(size_t)(blockIdx.x & (AZ_CTR_BUCKETS - 1)) * C_N + C_SKIPPED], 1ULL);
             if (n > 0 && !full) {
                 D.bStart[bb + bi] = start; D.bCount[bb + bi] = n;
                 D.bOwner[bb + bi] = node; D.bParent[bb + bi] = D.leaf_block[li];
                 D.nBlocks[t] = bi + 1; D.nEdges[t] = start + n;
                 if (node == NODE_ROOT) D.rootBlock[t] = bi; else D.eChild[tb + node] = bi;
-                atomicAdd(&D.ctr[C_EDGES], (unsigned long long)n);
+                atomicAdd(&D.ctr[(size_t)(blockIdx.x & (AZ_CTR_BUCKETS - 1)) * C_N + C_EDGES], (unsigned long long)n);
             }
             // node.update(value): raw value at the root, -player*value below it
             R add = root_expand ? v : (R)(-player) * v;
@@ -411,11 +411,11 @@ __global__ __launch_bounds__(64) void k_move(Dev D)
         D.pending[2 * g + 1] = mv;
         D.ply[g] = ply + 1;
         D.side[g] = side ^ 1;
-        atomicAdd(&D.ctr[C_MOVES], 1ULL);
+        atomicAdd(&D.ctr[(size_t)(blockIdx.x & (AZ_CTR_BUCKETS - 1)) * C_N + C_MOVES], 1ULL);
         if (over) {
             D.tr_winner[g] = win;
             D.phase[g] = PH_GAME_DONE;
-            atomicAdd(&D.ctr[C_GAMES], 1ULL);
+            atomicAdd(&D.ctr[(size_t)(blockIdx.x & (AZ_CTR_BUCKETS - 1)) * C_N + C_GAMES], 1ULL);
         } else {
             D.phase[g] = PH_NEED_START;
             D.dflag[g] = s.turns <= D.dirichlet_before;
