@@ -34,15 +34,22 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
 template <typename T>
 __global__ void k_planes_to_nhwc(const int8_t *planes, T *X0, int H, int W, const int32_t *__restrict__ rows)
 {
-    // board b of the batch is row rows[b] of `planes` (rows == nullptr: row b)
+    // board b of the batch is row rows[b] of `planes` (rows == nullptr: row b).  One thread per board point: 17 plane
+    // bytes in (coalesced across the points of a plane), CIN0 channels out as 16-byte stores.
     const int b = blockIdx.x, HW = H * W, PP = (H + 2) * (W + 2);
     const int8_t *src = planes + (size_t)(rows ? rows[b] : b) * 17 * HW;
-    for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < HW * CIN0; idx += blockDim.x * gridDim.y) {
-        int pix = idx / CIN0, c = idx - pix * CIN0;
-        int y = pix / W, x = pix - y * W;
-        float v = c < 17 ? (float)src[c * HW + pix] : 0.0f;
-        size_t o = ((size_t)b * PP + (y + 1) * (W + 2) + (x + 1)) * CIN0 + c;
-        if constexpr (sizeof(T) == 2) X0[o] = f2bf(v); else X0[o] = v;
+    for (int pix = blockIdx.y * blockDim.x + threadIdx.x; pix < HW; pix += blockDim.x * gridDim.y) {
+        const int y = pix / W, x = pix - y * W;
+        T v[CIN0];
+#pragma unroll
+        for (int c = 0; c < CIN0; c++) {
+            const float f = c < 17 ? (float)src[c * HW + pix] : 0.0f;
+            if constexpr (sizeof(T) == 2) v[c] = f2bf(f); else v[c] = f;
+        }
+        T *dst = X0 + ((size_t)b * PP + (y + 1) * (W + 2) + (x + 1)) * CIN0;
+        constexpr int PER = 16 / (int)sizeof(T);
+#pragma unroll
+        for (int q = 0; q < CIN0 / PER; q++) *reinterpret_cast<uint4 *>(dst + q * PER) = *reinterpret_cast<const uint4 *>(&v[q * PER]);
     }
 }
 
