@@ -32,8 +32,10 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
 // int8 planes (B,17,H,W) -> NHWC with halo, CIN0 channels (17 real + zeros)
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ void k_planes_to_nhwc(const int8_t *planes, T *X0, int H, int W, const int32_t *__restrict__ rows)
+__global__ void k_planes_to_nhwc(const int8_t *planes, T *X0, int H, int W, const int32_t *__restrict__ rows,
+                                 const int32_t *__restrict__ cnt)
 {
+    if (cnt && (int)blockIdx.x >= *cnt) return;  // batch size kept on the device: the grid covers the capacity
     // board b of the batch is row rows[b] of `planes` (rows == nullptr: row b).  One thread per board point: 17 plane
     // bytes in (coalesced across the points of a plane), CIN0 channels out as 16-byte stores.
     const int b = blockIdx.x, HW = H * W, PP = (H + 2) * (W + 2);
@@ -460,9 +462,18 @@ __device__ __forceinline__ int xcd_tile(int wg, int nwg)
 template <bool RESID, int NSP, int CIN = 256>
 __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
                                                                 const float *__restrict__ bias, const bf16_t *__restrict__ R,
-                                                                bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP, int npos)
+                                                                bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP, int npos,
+                                                                const int32_t *__restrict__ cnt)
 {
     constexpr int C = 256, NCC = CIN / 32, SLAB_BYTES = NSP * 128 * 64;  // C output channels, NCC 32-channel input chunks
+    // with the number of boards kept on the device the grid covers the capacity M / HW and tiles past the real count
+    // have nothing to do; the tile order is then the plain one, so that the live tiles still spread over all XCDs
+    const int tile = cnt ? (int)blockIdx.x : xcd_tile(blockIdx.x, gridDim.x);
+    if (cnt) {
+        const int nb = *cnt;
+        M = nb * HW; npos = nb * PP;
+        if (tile * 256 >= M) return;
+    }
 #ifdef STAMP
     int stamp_i = 0;
 #endif
@@ -472,7 +483,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
     int *srow = reinterpret_cast<int *>(smem + 147456 + 1024);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3;
-    const int m0 = xcd_tile(blockIdx.x, gridDim.x) * 256, W2 = Wd + 2;
+    const int m0 = tile * 256, W2 = Wd + 2;
     if (tid < 256) {
         int m = min(m0 + tid, M - 1);
         int b = m / HW, pix = m - b * HW, y = pix / Wd, x = pix - y * Wd;
@@ -693,36 +704,36 @@ static inline int conv_slab_span(int HW, int Wd, int PP)
 
 // stem: 32 (zero padded) input channels -> 256, one 32-channel chunk, same kernel
 static inline bool launch_v5_stem(const bf16_t *X, const bf16_t *Wt, const float *bias, bf16_t *Y, int M, int HW, int Wd, int PP,
-                                  hipStream_t st = 0);
+                                  hipStream_t st = 0, const int32_t *cnt = nullptr);
 
 static inline bool launch_v5(const bf16_t *X, const bf16_t *Wt, const float *bias, const bf16_t *R, bf16_t *Y, int M, int HW, int Wd,
-                             int PP, hipStream_t st = 0)
+                             int PP, hipStream_t st = 0, const int32_t *cnt = nullptr)
 {
     const int span = conv_slab_span(HW, Wd, PP);
     const int npos = (M / HW) * PP;
     dim3 g((M + 255) / 256), blk(512);
     if (span <= 3 * 128) {
-        if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<true, 3>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos);
-        else hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 3>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos);
+        if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<true, 3>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+        else hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 3>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
         return true;
     }
     if (span <= 4 * 128) {
-        if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<true, 4>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos);
-        else hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 4>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos);
+        if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<true, 4>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+        else hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 4>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
         return true;
     }
     return false;
 }
 
 static inline bool launch_v5_stem(const bf16_t *X, const bf16_t *Wt, const float *bias, bf16_t *Y, int M, int HW, int Wd, int PP,
-                                  hipStream_t st)
+                                  hipStream_t st, const int32_t *cnt)
 {
     const int span = conv_slab_span(HW, Wd, PP);
     const int npos = (M / HW) * PP;
     dim3 g((M + 255) / 256), blk(512);
     const bf16_t *R = nullptr;
-    if (span <= 3 * 128) { hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 3, 32>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos); return true; }
-    if (span <= 4 * 128) { hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 4, 32>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos); return true; }
+    if (span <= 3 * 128) { hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 3, 32>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt); return true; }
+    if (span <= 4 * 128) { hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 4, 32>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt); return true; }
     return false;
 }
 

@@ -32,6 +32,7 @@ struct az_engine {
     Tower *tower2 = nullptr;
     bool two_nets = false;
     int32_t *net_first = nullptr, *net_rows = nullptr, *net_cnt = nullptr;  // [G], [2][G], [2]
+    unsigned long long *net_tot = nullptr;  // [2] boards each network has evaluated, summed on the device
     // staging
     int32_t *st_a = nullptr, *st_b = nullptr, *st_c = nullptr, *st_d = nullptr, *st_e = nullptr;  // [max(G,64)] each
     uint8_t *st_bytes = nullptr;   // [G * max(O, 17*NC)]
@@ -199,7 +200,7 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     ok = ok && (h->st_a = dalloc<int32_t>(h, stn)) && (h->st_b = dalloc<int32_t>(h, stn)) &&
          (h->st_c = dalloc<int32_t>(h, stn)) && (h->st_d = dalloc<int32_t>(h, stn)) && (h->st_e = dalloc<int32_t>(h, stn));
     ok = ok && (h->net_first = dalloc<int32_t>(h, G)) && (h->net_rows = dalloc<int32_t>(h, 2 * (size_t)G)) &&
-         (h->net_cnt = dalloc<int32_t>(h, 2));
+         (h->net_cnt = dalloc<int32_t>(h, 2)) && (h->net_tot = dalloc<unsigned long long>(h, 2));
     h->st_bytes_n = (size_t)G * std::max(O, 17 * NC);
     ok = ok && (h->st_bytes = dalloc<uint8_t>(h, h->st_bytes_n));
     if (!ok) {
@@ -450,6 +451,14 @@ extern "C" int az_leaf_batch(az_engine *h, int8_t *planes, uint8_t *valid)
     return AZ_OK;
 }
 
+// Two-network rounds without a read-back: both towers take the device-side batch size, and the slot count is large
+// enough that the slab kernels (the only ones that read it) are the right choice even for a half-empty batch.
+static bool two_nets_async(const az_engine *h)
+{
+    return h->two_nets && h->tower && h->tower2 && !h->conv_profile &&
+           tower_takes_device_count(h->tower, h->D.G) && tower_takes_device_count(h->tower2, h->D.G);
+}
+
 // priors / values: host arrays of the engine's statistic type (f64 says which the caller passed), or NULL = run the tower
 static int evaluate(az_engine *h, const void *priors, const void *values, int f64 = 0)
 {
@@ -469,11 +478,24 @@ static int evaluate(az_engine *h, const void *priors, const void *values, int f6
     if (h->two_nets) {
         if (h->D.K > 1) return set_err(h, AZ_ERR_ARG, "two-network matches run one leaf per tree per round (leaves_per_round = 1)");
         if (!h->tower2 || !tower_ready(h->tower2)) return set_err(h, AZ_ERR_NO_WEIGHTS, "two-network match: network 1 has no weights");
-        hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, h->stream, h->D, (const int32_t *)h->net_first, h->net_rows, h->net_cnt);
+        hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, h->stream, h->D, (const int32_t *)h->net_first, h->net_rows, h->net_cnt,
+                           h->net_tot);
+        Tower *tw[2] = {h->tower, h->tower2};
+        if (two_nets_async(h)) {
+            // the towers read their batch sizes from device memory: nothing comes back to the host, rounds can be queued
+            for (int net = 0; net < 2; net++) {
+                if (tower_forward(tw[net], h->D.planes, G, (float *)h->D.priors, (float *)h->D.values, h->stream, terr,
+                                  h->net_rows + (size_t)net * G, h->net_cnt + net) != 0) {
+                    h->error = "tower: " + terr;
+                    return AZ_ERR_HIP;
+                }
+                h->tower_calls++;
+            }
+            return AZ_OK;
+        }
         int32_t cnt[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(cnt, h->net_cnt, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        Tower *tw[2] = {h->tower, h->tower2};
         for (int net = 0; net < 2; net++) {
             if (cnt[net] == 0) continue;
             if (tower_forward(tw[net], h->D.planes, cnt[net], (float *)h->D.priors, (float *)h->D.values, h->stream, terr, h->net_rows + (size_t)net * G) != 0) {
@@ -481,7 +503,6 @@ static int evaluate(az_engine *h, const void *priors, const void *values, int f6
                 return AZ_ERR_HIP;
             }
             h->tower_calls++;
-            h->tower_evals += cnt[net];
         }
         return AZ_OK;
     }
@@ -661,7 +682,7 @@ extern "C" int az_selfplay_run(az_engine *h, int32_t n_rounds)
     HIPCHK(hipSetDevice(h->cfg.device));
     // per-launch conv timing reuses one set of events per forward and the two-network split reads counts back every
     // round, so those modes keep the host in step with the device; otherwise rounds are queued AZ_EVQ deep
-    const int depth = (h->conv_profile || h->two_nets) ? 1 : AZ_EVQ;
+    const int depth = (h->conv_profile || (h->two_nets && !two_nets_async(h))) ? 1 : AZ_EVQ;
     for (int r = 0; r < n_rounds; r++) {
         if (h->ev_pending >= depth) { int rc = drain_round(h); if (rc) return rc; }
         hipEvent_t *ev = h->ev[(h->ev_head + h->ev_pending) % AZ_EVQ];
@@ -920,6 +941,11 @@ extern "C" int az_counters_get(az_engine *h, az_counters *out)
     out->rule_moves = c[C_RULEMOVES]; out->expansions_skipped = c[C_SKIPPED];
     out->tower_ms = h->tower_ms; out->select_ms = h->select_ms; out->finish_ms = h->finish_ms;
     out->tower_calls = h->tower_calls; out->tower_evals = h->tower_evals;
+    {
+        unsigned long long tot[2];
+        HIPCHK(hipMemcpy(tot, h->net_tot, sizeof tot, hipMemcpyDeviceToHost));
+        out->tower_evals += tot[0] + tot[1];
+    }
     out->conv_ms = 0; out->conv_launches = 0; out->conv_flops_per_launch = 0;
     if (h->tower) {
         unsigned long long n = 0;
@@ -938,6 +964,7 @@ extern "C" int az_counters_reset(az_engine *h)
     HIPCHK(hipMemset(h->D.ctr, 0, sizeof(unsigned long long) * AZ_CTR_BUCKETS * (C_N + 1)));
     h->tower_ms = h->select_ms = h->finish_ms = 0;
     h->tower_calls = h->tower_evals = h->steps = 0;
+    HIPCHK(hipMemset(h->net_tot, 0, 2 * sizeof(unsigned long long)));
     if (h->tower) { double a; unsigned long long b; tower_profile_read(h->tower, &a, &b, true); }
     return AZ_OK;
 }

@@ -722,7 +722,7 @@ __global__ __launch_bounds__(64) void k_choose(Dev D, int g, int side, double u,
 // rows[net * G + i] = i-th slot of that network, counts[net] = length.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_partition(Dev D, const int32_t *__restrict__ net_of_first, int32_t *__restrict__ rows,
-                                                    int32_t *__restrict__ counts)
+                                                    int32_t *__restrict__ counts, unsigned long long *__restrict__ totals)
 {
     __shared__ int wtot[2][16];
     __shared__ int base[2];
@@ -750,5 +750,5 @@ __global__ __launch_bounds__(1024) void k_partition(Dev D, const int32_t *__rest
         }
         __syncthreads();
     }
-    if (tid < 2) counts[tid] = base[tid];
+    if (tid < 2) { counts[tid] = base[tid]; totals[tid] += (unsigned long long)base[tid]; }  // one block: no race
 }

@@ -15,8 +15,11 @@ int tower_load(Tower *t, const float *host_blob, size_t n_floats, hipStream_t st
 bool tower_ready(const Tower *t);
 // planes_dev int8 (*,17,H,W); priors_dev (*,O), values_dev (*) float32.  Board b of the batch of B is row
 // rows_dev[b] of those arrays (rows_dev == nullptr: row b), so a subset of a larger leaf batch can be evaluated in place.
+// count_dev (optional, only when tower_takes_device_count): the real number of boards lives in device memory and B is
+// the capacity the grids are sized for, so the caller does not have to read the count back before launching.
 int tower_forward(Tower *t, const int8_t *planes_dev, int B, float *priors_dev, float *values_dev, hipStream_t st,
-                  std::string &err, const int32_t *rows_dev = nullptr);
+                  std::string &err, const int32_t *rows_dev = nullptr, const int32_t *count_dev = nullptr);
+bool tower_takes_device_count(const Tower *t, int B);
 double tower_flops_per_eval(const Tower *t);
 // names/durations of the dominant kernel for the roofline line
 double tower_conv_flops_per_launch(const Tower *t, int B);

@@ -58,8 +58,10 @@ static inline bf16_t h_f2bf(float f)
 // ---------------------------------------------------------------------------
 template <typename T, bool ONEPASS>
 __global__ __launch_bounds__(256) void k_head_conv(const T *__restrict__ X, const float *__restrict__ wh, const float *__restrict__ bh,
-                                                   float *__restrict__ hp, float *__restrict__ hv, int HW, int Wd, int PP, int C, int LPP)
+                                                   float *__restrict__ hp, float *__restrict__ hv, int HW, int Wd, int PP, int C, int LPP,
+                                                   const int32_t *__restrict__ cnt)
 {
+    if (cnt && (int)blockIdx.x >= *cnt) return;
     constexpr int EPL = 16 / (int)sizeof(T);  // channels per 16-byte load
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int W2 = Wd + 2;
@@ -120,8 +122,10 @@ __global__ __launch_bounds__(384) void k_head_fc(const float *__restrict__ hp, c
                                                  const float *__restrict__ w1, const float *__restrict__ b1,
                                                  const float *__restrict__ w2, const float *__restrict__ b2,
                                                  float *__restrict__ priors, float *__restrict__ values, int HW, int O, int B,
-                                                 const int32_t *__restrict__ rows)
+                                                 const int32_t *__restrict__ rows, const int32_t *__restrict__ cnt)
 {
+    if (cnt) B = *cnt;
+    if ((int)blockIdx.x * FCB >= B) return;
     __shared__ float sp[FCB][2 * 361 + 2];
     __shared__ float sv[FCB][361 + 3];
     __shared__ float part[6][FCB][384];
@@ -341,12 +345,19 @@ int tower_load(Tower *t, const float *blob, size_t n, hipStream_t st, std::strin
 }
 
 template <typename T>
-static void launch_conv(const Tower *t, const T *X, const T *Wt, const float *bias, const T *R, T *Y, int B, int cin, hipStream_t st);
+static void launch_conv(const Tower *t, const T *X, const T *Wt, const float *bias, const T *R, T *Y, int B, int cin, hipStream_t st,
+                        const int32_t *cnt = nullptr);
 
 template <>
 void launch_conv<bf16_t>(const Tower *t, const bf16_t *X, const bf16_t *Wt, const float *bias, const bf16_t *R, bf16_t *Y, int B,
-                         int cin, hipStream_t st)
+                         int cin, hipStream_t st, const int32_t *cnt)
 {
+    if (cnt) {  // device-side batch size: only the slab kernels take it (tower_takes_device_count() said they apply)
+        const int Mc = B * t->HW;
+        if (cin == CIN0) launch_v5_stem(X, Wt, bias, Y, Mc, t->HW, t->W, t->PP, st, cnt);
+        else launch_v5(X, Wt, bias, R, Y, Mc, t->HW, t->W, t->PP, st, cnt);
+        return;
+    }
     const int M = B * t->HW;
     dim3 grid((M + 127) / 128, t->C / 128), block(256);
     // a few positions only: spread them over many small workgroups instead of a handful of 256-point tiles
@@ -374,7 +385,7 @@ void launch_conv<bf16_t>(const Tower *t, const bf16_t *X, const bf16_t *Wt, cons
 
 template <>
 void launch_conv<float>(const Tower *t, const float *X, const float *Wt, const float *bias, const float *R, float *Y, int B, int cin,
-                        hipStream_t st)
+                        hipStream_t st, const int32_t *)
 {
     const int M = B * t->HW;
     dim3 grid((M + 63) / 64, t->C / 64), block(256);
@@ -385,20 +396,21 @@ void launch_conv<float>(const Tower *t, const float *X, const float *Wt, const f
 }
 
 template <typename T>
-static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float *values, hipStream_t st, const int32_t *rows)
+static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float *values, hipStream_t st, const int32_t *rows,
+                     const int32_t *cnt)
 {
     const size_t C = t->C;
     T *X0 = (T *)t->X0, *X = (T *)t->X, *Tm = (T *)t->T, *Y = (T *)t->Y;
     const int ysplit = B < 64 ? 8 : 1;  // few boards: several workgroups per board in the memory-bound kernels
-    hipLaunchKernelGGL((k_planes_to_nhwc<T>), dim3(B, ysplit), dim3(256), 0, st, planes, X0, t->H, t->W, rows);
-    launch_conv<T>(t, X0, (const T *)t->w_stem, t->b_stem, (const T *)nullptr, X, B, CIN0, st);
+    hipLaunchKernelGGL((k_planes_to_nhwc<T>), dim3(B, ysplit), dim3(256), 0, st, planes, X0, t->H, t->W, rows, cnt);
+    launch_conv<T>(t, X0, (const T *)t->w_stem, t->b_stem, (const T *)nullptr, X, B, CIN0, st, cnt);
     for (int l = 0; l < t->NB; l++) {
         const T *w1 = (const T *)t->w_conv + (size_t)(2 * l) * C * 9 * C;
         const T *w2 = (const T *)t->w_conv + (size_t)(2 * l + 1) * C * 9 * C;
         if (t->profile) hipEventRecord(t->evs[t->evs_used++], st);
-        launch_conv<T>(t, X, w1, t->b_conv + (size_t)(2 * l) * C, (const T *)nullptr, Tm, B, (int)C, st);
+        launch_conv<T>(t, X, w1, t->b_conv + (size_t)(2 * l) * C, (const T *)nullptr, Tm, B, (int)C, st, cnt);
         if (t->profile) { hipEventRecord(t->evs[t->evs_used++], st); hipEventRecord(t->evs[t->evs_used++], st); }
-        launch_conv<T>(t, Tm, w2, t->b_conv + (size_t)(2 * l + 1) * C, X, Y, B, (int)C, st);
+        launch_conv<T>(t, Tm, w2, t->b_conv + (size_t)(2 * l + 1) * C, X, Y, B, (int)C, st, cnt);
         if (t->profile) hipEventRecord(t->evs[t->evs_used++], st);
         T *tmp = X; X = Y; Y = tmp;
     }
@@ -408,24 +420,31 @@ static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float
         while (chunks % lpp) lpp >>= 1;                     // largest power of two <= 64 dividing it
         if (chunks == lpp)
             hipLaunchKernelGGL((k_head_conv<T, true>), dim3(B, ysplit), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, t->hp, t->hv, t->HW,
-                               t->W, t->PP, (int)C, lpp);
+                               t->W, t->PP, (int)C, lpp, cnt);
         else
             hipLaunchKernelGGL((k_head_conv<T, false>), dim3(B, ysplit), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, t->hp, t->hv, t->HW,
-                               t->W, t->PP, (int)C, lpp);
+                               t->W, t->PP, (int)C, lpp, cnt);
     }
     hipLaunchKernelGGL(k_head_fc, dim3((B + FCB - 1) / FCB), dim3(384), 0, st, t->hp, t->hv, t->w_pfc, t->b_pfc, t->w_v1, t->b_v1, t->w_v2,
-                       t->b_v2, priors, values, t->HW, t->O, B, rows);
+                       t->b_v2, priors, values, t->HW, t->O, B, rows, cnt);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+bool tower_takes_device_count(const Tower *t, int B)
+{
+    return t->dtype == 1 && t->C == 256 && CIN0 == 32 && conv_slab_span(t->HW, t->W, t->PP) <= 4 * 128 && B >= 1 && B <= t->maxB &&
+           (size_t)B * t->HW > 4 * (size_t)SMALL_BATCH_POINTS;  // below that a half-empty batch belongs to the small-batch kernels
+}
+
 int tower_forward(Tower *t, const int8_t *planes_dev, int B, float *priors_dev, float *values_dev, hipStream_t st, std::string &err,
-                  const int32_t *rows_dev)
+                  const int32_t *rows_dev, const int32_t *count_dev)
 {
     if (!t->ready) { err = "weights not loaded"; return -1; }
     if (B < 1 || B > t->maxB) { err = "batch exceeds the tower's activation buffers"; return -1; }
+    if (count_dev && !tower_takes_device_count(t, B)) { err = "this tower shape needs the batch size on the host"; return -1; }
     t->evs_used = 0;
-    int rc = t->dtype == 1 ? forward_t<bf16_t>(t, planes_dev, B, priors_dev, values_dev, st, rows_dev)
-                           : forward_t<float>(t, planes_dev, B, priors_dev, values_dev, st, rows_dev);
+    int rc = t->dtype == 1 ? forward_t<bf16_t>(t, planes_dev, B, priors_dev, values_dev, st, rows_dev, count_dev)
+                           : forward_t<float>(t, planes_dev, B, priors_dev, values_dev, st, rows_dev, count_dev);
     if (rc) err = std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError());
     return rc;
 }

@@ -15,7 +15,9 @@ def _blobs(H, W, O, NB, C):
 
 
 @pytest.mark.parametrize("H,C,dtype,G,P,max_turn", [(5, 128, "fp32", 6, 10, 12), (9, 256, "bf16", 6, 10, 12),
-                                                   (5, 128, "bf16", 1500, 3, 5)])   # > 1024 slots: several partition passes
+                                                   (5, 128, "bf16", 1500, 3, 5),    # > 1024 slots: several partition passes
+                                                   (9, 256, "bf16", 320, 3, 5)])    # large enough for the queued rounds whose towers
+                                                                                    # read their batch sizes from device memory
 def test_two_network_routing_is_exact(H, C, dtype, G, P, max_turn):
     from alphazero_amd.engine import Engine
     NB, O = 1, H * H + 1
