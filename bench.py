@@ -241,12 +241,26 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only; at N>1 the other ranks would idle behind it
             out["cpu_baseline"] = cpu_baseline(args.game, H, args.k, args.blocks, args.channels, args.sims)
-        print(json.dumps(out))
+        _emit(json.dumps(out))
     eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
+# The one JSON line must be the only thing on stdout, but libraries write there too (RCCL prints a version banner when
+# its first communicator is made): file descriptor 1 is pointed at stderr for the whole run and the result line goes
+# to the saved descriptor.
+_REAL_STDOUT = None
+
+
+def _emit(line):
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (line + "\n").encode())
+
+
 if __name__ == "__main__":
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     main()
