@@ -466,14 +466,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
                                                                 const int32_t *__restrict__ cnt)
 {
     constexpr int C = 256, NCC = CIN / 32, SLAB_BYTES = NSP * 128 * 64;  // C output channels, NCC 32-channel input chunks
-    // with the number of boards kept on the device the grid covers the capacity M / HW and tiles past the real count
-    // have nothing to do; the tile order is then the plain one, so that the live tiles still spread over all XCDs
-    const int tile = cnt ? (int)blockIdx.x : xcd_tile(blockIdx.x, gridDim.x);
+    // with the number of boards kept on the device the grid covers the capacity M / HW: the first ceil(M / 256)
+    // workgroups (still round-robin over the XCDs) share the live tiles, the others have nothing to do
+    int nwg = gridDim.x;
     if (cnt) {
         const int nb = *cnt;
         M = nb * HW; npos = nb * PP;
-        if (tile * 256 >= M) return;
+        nwg = (M + 255) >> 8;
+        if ((int)blockIdx.x >= nwg) return;
     }
+    const int tile = xcd_tile(blockIdx.x, nwg);
 #ifdef STAMP
     int stamp_i = 0;
 #endif

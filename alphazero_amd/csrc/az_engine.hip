@@ -31,6 +31,7 @@ struct az_engine {
     // two-network matches: second weight set, which network moves first in each slot, per-network leaf lists
     Tower *tower2 = nullptr;
     bool two_nets = false;
+    bool compact = true;  // run the tower only on the leaf rows that need it, when its kernels can take the count from the device
     int32_t *net_first = nullptr, *net_rows = nullptr, *net_cnt = nullptr;  // [G], [2][G], [2]
     unsigned long long *net_tot = nullptr;  // [2] boards each network has evaluated, summed on the device
     // staging
@@ -199,7 +200,7 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     const size_t stn = std::max(G, 64);
     ok = ok && (h->st_a = dalloc<int32_t>(h, stn)) && (h->st_b = dalloc<int32_t>(h, stn)) &&
          (h->st_c = dalloc<int32_t>(h, stn)) && (h->st_d = dalloc<int32_t>(h, stn)) && (h->st_e = dalloc<int32_t>(h, stn));
-    ok = ok && (h->net_first = dalloc<int32_t>(h, G)) && (h->net_rows = dalloc<int32_t>(h, 2 * (size_t)G)) &&
+    ok = ok && (h->net_first = dalloc<int32_t>(h, G)) && (h->net_rows = dalloc<int32_t>(h, 2 * (size_t)G * std::max(1, (int)cfg->leaves_per_round))) &&
          (h->net_cnt = dalloc<int32_t>(h, 2)) && (h->net_tot = dalloc<unsigned long long>(h, 2));
     h->st_bytes_n = (size_t)G * std::max(O, 17 * NC);
     ok = ok && (h->st_bytes = dalloc<uint8_t>(h, h->st_bytes_n));
@@ -504,6 +505,17 @@ static int evaluate(az_engine *h, const void *priors, const void *values, int f6
             }
             h->tower_calls++;
         }
+        return AZ_OK;
+    }
+    if (h->compact && !h->conv_profile && tower_takes_device_count(h->tower, LG)) {
+        // terminal leaves and idle slots stay out of the batch: the surviving rows are listed on the device and the
+        // tower's kernels read their number there (per-launch conv timing measures full batches, so it turns this off)
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, h->D, LG, h->net_rows, h->net_cnt, h->net_tot);
+        if (tower_forward(h->tower, h->D.planes, LG, (float *)h->D.priors, (float *)h->D.values, h->stream, terr, h->net_rows, h->net_cnt) != 0) {
+            h->error = "tower: " + terr;
+            return AZ_ERR_HIP;
+        }
+        h->tower_calls++;
         return AZ_OK;
     }
     if (tower_forward(h->tower, h->D.planes, LG, (float *)h->D.priors, (float *)h->D.values, h->stream, terr) != 0) {
@@ -916,6 +928,15 @@ extern "C" int az_tower_profile(az_engine *h, int32_t on)
     HIPCHK(hipStreamSynchronize(h->stream));
     tower_set_profile(h->tower, on != 0);
     h->conv_profile = on != 0;
+    return AZ_OK;
+}
+
+extern "C" int az_tower_leaf_compaction(az_engine *h, int32_t on)
+{
+    if (!h) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->compact = on != 0;
     return AZ_OK;
 }
 

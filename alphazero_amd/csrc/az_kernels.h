@@ -715,6 +715,46 @@ __global__ __launch_bounds__(64) void k_choose(Dev D, int g, int side, double u,
     if (lane_id() == 0) out[0] = mv;
 }
 
+// A leaf row needs the evaluator unless it is a terminal state below the root: that one takes its value from the rules
+// (mcts.py:229-231) and never looks at priors or value.  (The reference still calls its evaluator there and throws the
+// answer away.)
+__device__ __forceinline__ bool leaf_needs_eval(const Dev &D, int row)
+{
+    return D.leaf_valid[row] && (D.leaf_root[row] || !D.leaf_end[row]);
+}
+
+// Rows that need the evaluator, packed to the front of `rows` in row order; their number goes to count[0] and is added
+// to total[0].  One workgroup, n_rows = leaves_per_round * n_slots.
+__global__ __launch_bounds__(1024) void k_compact(Dev D, int n_rows, int32_t *__restrict__ rows, int32_t *__restrict__ count,
+                                                  unsigned long long *__restrict__ total)
+{
+    __shared__ int wtot[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < n_rows; r0 += 1024) {
+        const int r = r0 + tid;
+        const bool live = r < n_rows && leaf_needs_eval(D, r);
+        const unsigned long long m = __ballot(live);
+        if (lane == 0) wtot[wave] = __popcll(m);
+        __syncthreads();
+        if (live) {
+            int off = base;
+            for (int w = 0; w < wave; w++) off += wtot[w];
+            rows[off + __popcll(m & ((1ull << lane) - 1ull))] = r;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; w++) t += wtot[w];
+            base += t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { count[0] = base; total[0] += (unsigned long long)base; }
+}
+
 // ---------------------------------------------------------------------------
 // Two-network matches (train/parallel/evaluator.py:81-84: Game(chal, best) or Game(best, chal)).
 // Splits the round's valid leaves by the network that owns the searching tree: side s of slot g is
@@ -732,7 +772,7 @@ __global__ __launch_bounds__(1024) void k_partition(Dev D, const int32_t *__rest
     for (int g0 = 0; g0 < D.G; g0 += 1024) {
         const int g = g0 + tid;
         int net = -1;
-        if (g < D.G && D.leaf_valid[g]) net = (net_of_first[g] ^ D.side[g]) & 1;
+        if (g < D.G && leaf_needs_eval(D, g)) net = (net_of_first[g] ^ D.side[g]) & 1;
         const unsigned long long m0 = __ballot(net == 0), m1 = __ballot(net == 1);
         if (lane == 0) { wtot[0][wave] = __popcll(m0); wtot[1][wave] = __popcll(m1); }
         __syncthreads();

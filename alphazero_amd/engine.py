@@ -259,6 +259,9 @@ class Engine:
     def tower_profile(self, on=True):
         self._ck(self._L.az_tower_profile(self._h, int(on)))
 
+    def tower_leaf_compaction(self, on=True):
+        self._ck(self._L.az_tower_leaf_compaction(self._h, int(on)))
+
     def tower_flops_per_eval(self):
         return self._L.az_tower_flops_per_eval(self._h)
 

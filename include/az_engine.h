@@ -215,6 +215,11 @@ double az_tower_flops_per_eval(az_engine *h);
 /* on=1: bracket every residual-tower convolution launch of az_selfplay_run with HIP events on the
  * launch stream and accumulate conv_ms / conv_launches in az_counters (measurement only) */
 int az_tower_profile(az_engine *h, int32_t on);
+/* on=1 (the default): a round's tower pass covers only the leaf rows that need it. The reference calls its evaluator for
+ * every playout and throws the answer away at a finished game (search/mcts.py:204-211 against :229-231); results are
+ * the same either way, on=0 only serves comparisons. Applies where the tower's kernels take the row count from device
+ * memory (256-channel bf16 tower, large batches) and never while az_tower_profile is on. */
+int az_tower_leaf_compaction(az_engine *h, int32_t on);
 
 /* ---- measurement ------------------------------------------------------ */
 int az_counters_get(az_engine *h, az_counters *out);

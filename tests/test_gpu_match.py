@@ -83,3 +83,33 @@ def test_batched_match_counts_like_the_reference():
     assert out["colors_of_new"] == gating_colors(7)
     assert len(out["winners"]) == 7 and all(w in (-1, 0, 1) for w in out["winners"])
     assert (out["win_counter"], out["num_not_tie"], out["accepted"]) == gating_verdict(out["winners"], out["colors_of_new"])
+
+
+@pytest.mark.parametrize("game,H,k,G,P,rounds", [("reversi", 8, 0, 400, 6, 70 * 7), ("mnk", 8, 4, 400, 5, 66 * 6)])
+def test_leaf_compaction_changes_nothing_but_the_work(game, H, k, G, P, rounds):
+    """Whole games with many finished-game leaves near the end: the tower run on the compacted rows only (device-side
+    row list and count) gives the same trajectories, bit for bit, as the tower run on every row, and evaluates fewer
+    boards."""
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.network.model import fold_to_blob, random_net
+    O = H * H + (0 if game == "mnk" else 1)
+    blob = fold_to_blob(random_net(H, H, O, 1, 256, seed=9, perturb_bn=True))
+    out = []
+    for compact in (True, False):
+        eng = Engine(game, H, H, k, n_slots=G, max_playout=P, transform_types=8, dirichlet_before=4, max_turn=400,
+                     record_trajectories=True, seed=5, num_blocks=1, channels=256, tower_dtype="bf16")
+        eng.tower_load(blob)
+        eng.tower_leaf_compaction(compact)
+        eng.selfplay_start()
+        eng.selfplay_run(rounds)
+        plies, done = eng.selfplay_status()
+        assert np.all(done == 1)
+        c = eng.counters()
+        out.append(([eng.trajectory_pop(s) for s in range(G)], c["tower_evals"], c["evals"], plies))
+        eng.close()
+    (ta, ea, na, pa), (tb, eb, nb, pb) = out
+    assert np.array_equal(pa, pb) and na == nb
+    for a, b in zip(ta, tb):
+        assert np.array_equal(a["moves"], b["moves"]) and np.array_equal(a["visits"], b["visits"]) and a["winner"] == b["winner"]
+    assert eb == rounds * G            # every row of every round
+    assert ea < na <= eb               # only live, non-terminal leaves: fewer than the playouts counted
