@@ -31,6 +31,15 @@ def game_config_to_engine_kwargs(game_config):
                 d_alpha=float(game_config.get("d_alpha", 0.03)), d_epsilon=float(game_config.get("d_epsilon", 0.25)))
 
 
+def slots_for_whole_tile_rounds(n_max, board_height, board_width, compute_units=256, tile_points=256):
+    """Largest slot count <= n_max whose board points fill a whole number of rounds of the tower's conv tiles
+    (256 points each, one tile per compute unit at a time): a partly filled last round costs as much as a full one
+    in every conv launch (4096 slots of 15x15 are 14.06 rounds, 4077 are 14).  n_max itself when it is below one round."""
+    hw = board_height * board_width
+    rounds = (n_max * hw) // (tile_points * compute_units)
+    return (rounds * tile_points * compute_units) // hw if rounds >= 1 else n_max
+
+
 class Engine:
     def __init__(self, game, board_height, board_width, k=0, n_slots=1, max_playout=0, transform_types=0,
                  dirichlet_before=30, max_turn=400, d_alpha=0.03, d_epsilon=0.25, tree_edge_cap=0, tree_block_cap=0,

@@ -152,7 +152,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from alphazero_amd.engine import Engine
+    from alphazero_amd.engine import Engine, slots_for_whole_tile_rounds
     from alphazero_amd.network.model import fold_to_blob, random_net
     from alphazero_amd import parallel
 
@@ -167,8 +167,7 @@ def main():
         # the tower's conv tiles are 256 board points; pick the largest game count whose tiles fill a whole number of
         # rounds over the CUs (no partly idle last round in each of the 40 conv launches): 3993 games of 19x19 = 22 rounds
         cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
-        rounds = (gmax * H * H) // (256 * cus)
-        args.games = (rounds * 256 * cus) // (H * H) if rounds >= 1 else gmax
+        args.games = slots_for_whole_tile_rounds(gmax, H, H, cus)
     eng = Engine(args.game, H, H, args.k, n_slots=args.games, max_playout=args.sims, transform_types=8, dirichlet_before=30,
                  max_turn=400, d_alpha=0.03, d_epsilon=0.25, seed=1000 + rank, record_trajectories=True,
                  num_blocks=args.blocks, channels=args.channels, tower_dtype=args.dtype, device=local_rank)

@@ -25,3 +25,15 @@ def test_measured_traffic_scales_with_boards():
     t2, _ = bench.measured_traffic(7986, 19, 256)
     assert t > 1e9 and abs(t2 - 2 * t) <= 2 and "FETCH_SIZE" in src
     assert bench.measured_traffic(1024, 9, 256) == (None, None)      # other board size: no counters taken
+
+
+def test_slot_count_for_whole_rounds_of_conv_tiles():
+    from alphazero_amd.engine import slots_for_whole_tile_rounds
+    assert slots_for_whole_tile_rounds(4096, 19, 19) == 3993          # 22 rounds of 256 tiles x 256 points
+    assert slots_for_whole_tile_rounds(4096, 8, 8) == 4096            # exactly 4 rounds
+    assert slots_for_whole_tile_rounds(4096, 15, 15) == 4077          # 14 rounds
+    assert slots_for_whole_tile_rounds(100, 19, 19) == 100            # below one round: unchanged
+    for n in (300, 1000, 5000):
+        m = slots_for_whole_tile_rounds(n, 9, 9)
+        rounds = (n * 81) // 65536
+        assert m <= n and (m == n if rounds == 0 else m * 81 <= rounds * 65536 < (m + 1) * 81)
