@@ -355,9 +355,35 @@ def main64():
     save("search64_ttt_uniform", search_trace("tttu", "mnk", 3, 3, 3, 0, 100, 30, 400, 34, 10 ** 9, real64="uniform"))
 
 
+def main_shapes():
+    """Hand-built Go shapes, each checked here against what the shape is meant to show before it is saved."""
+    def seq(moves):
+        return [25 if m is None else m[0] * 5 + m[1] for m in moves]
+    # snapback: B throws in at (0,1), W takes it with (0,0) and is left with a 4-stone chain on one liberty, so no ko is
+    # marked (go.py:547-550) and B retakes at (0,1), capturing four
+    snap = [(3, 0), (1, 0), (2, 1), (2, 0), (1, 2), (1, 1), (4, 4), (0, 2), (0, 1), (0, 0), (0, 1), (4, 0), None, None, None]
+    d = rules_trace("go", 5, 5, None, 0, 100, moves=seq(snap), feat_every=2)
+    assert d["ko"][10] == -1 and d["masks"][10][1] == 1            # after W's capture: no ko, (0,1) playable
+    assert tuple(d["pris"][10]) == (1, 0) and tuple(d["pris"][11]) == (1, 4) and d["final_is_end"] == 1
+    save("rules_go5_snapback", d)
+    # a two-stone capture, a plain suicide point for either side, and a stone played onto a point without liberties
+    # that is legal because it captures (and marks a ko)
+    sui = [(1, 0), (0, 0), (1, 1), (0, 1), (0, 2), (4, 4), (0, 1), (4, 3), (4, 0), (3, 0), (2, 2), (4, 1), (3, 1), (2, 0),
+           (4, 2), (0, 3), (4, 0), (0, 4), None, None, None]
+    d = rules_trace("go", 5, 5, None, 0, 100, moves=seq(sui), feat_every=2)
+    assert tuple(d["pris"][5]) == (0, 2)                            # B took two stones with (0,2)
+    assert d["masks"][7][0] == 0                                    # W may not play the corner (suicide)
+    assert d["masks"][12][20] == 0 and d["masks"][12][0] == 1       # B may not play (4,0), may fill its own corner
+    assert d["masks"][16][20] == 1 and d["boards"][16][4][0] == 0   # (4,0) has no empty neighbour but captures (4,1)
+    assert d["ko"][17] == 21 and d["masks"][17][21] == 0 and tuple(d["pris"][17]) == (1, 3)
+    save("rules_go5_suicide", d)
+
+
 def main():
     if "--only64" in sys.argv:
         return main64()
+    if "--only-shapes" in sys.argv:
+        return main_shapes()
     # ---- transforms: label tables of ReverseTransformer and forward board maps
     tabs = {}
     for n in (3, 5, 7, 8, 9, 19):
@@ -404,6 +430,7 @@ def main():
     ]
     save("rules_go5_double_capture", rules_trace("go", 5, 5, None, 0, 100, moves=[x * 5 + y for x, y in seq] + [25, 25, 25],
                                                  feat_every=3))
+    main_shapes()
     passes = [25, 25, 25, 0]
     save("rules_go5_passes", rules_trace("go", 5, 5, None, 0, 100, moves=passes, feat_every=1))
     # SGF main lines shipped with the reference's tests (19x19, real games with captures/ko)
