@@ -377,6 +377,10 @@ def main_shapes():
     assert d["masks"][16][20] == 1 and d["boards"][16][4][0] == 0   # (4,0) has no empty neighbour but captures (4,1)
     assert d["ko"][17] == 21 and d["masks"][17][21] == 0 and tuple(d["pris"][17]) == (1, 3)
     save("rules_go5_suicide", d)
+    # a whole Reversi game (6x6, 16 playouts per move) in which the side to move has to pass twice
+    d = search_trace("rev6", "reversi", 6, 6, None, 8, 16, 30, 400, 40, 10 ** 9)
+    assert int((d["moves"] == 36).sum()) == 2
+    save("search_reversi6_pass", d)
 
 
 def main():
