@@ -381,6 +381,10 @@ def main_shapes():
     d = search_trace("rev6", "reversi", 6, 6, None, 8, 16, 30, 400, 40, 10 ** 9)
     assert int((d["moves"] == 36).sum()) == 2
     save("search_reversi6_pass", d)
+    # a drawn tic-tac-toe game through gameplay.Game: get_history labels a draw like a White win (gameplay.py:93)
+    d = search_trace("tttd", "mnk", 3, 3, 3, 0, 100, 30, 400, 61, 10 ** 9, use_game_class=True)
+    assert d["winner"] == 0 and len(d["moves"]) == 9 and list(d["hist_result"][:2]) == [-1.0, 1.0]
+    save("search_ttt_draw", d)
 
 
 def main():

@@ -63,7 +63,7 @@ def _restore(saved):
     mcts.randint, mcts.random_variate_dirichlet, mcts.weighted_random_choice = saved
 
 
-@pytest.mark.parametrize("name,seed", [("search_ttt_game", 21), ("search_reversi_game", 24)])
+@pytest.mark.parametrize("name,seed", [("search_ttt_game", 21), ("search_reversi_game", 24), ("search_ttt_draw", 61)])
 def test_game_class_reproduces_reference_game(name, seed):
     g = load_golden(name)
     game, H, W, k, O = str(g["game"]), int(g["H"]), int(g["W"]), int(g["k"]), int(g["O"])

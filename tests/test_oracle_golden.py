@@ -125,7 +125,7 @@ def test_search_trace(name):
         assert st.winner() == g["winner"]
 
 
-@pytest.mark.parametrize("name", ["search_ttt_game", "search_reversi_game"])
+@pytest.mark.parametrize("name", ["search_ttt_game", "search_reversi_game", "search_ttt_draw"])
 def test_play_game_and_history(name):
     """oz_play_game == Game.start; trajectory -> Game.get_history arrays (gameplay.py:73-94)."""
     g = load_golden(name)
