@@ -385,6 +385,11 @@ def main_shapes():
     d = search_trace("tttd", "mnk", 3, 3, 3, 0, 100, 30, 400, 61, 10 ** 9, use_game_class=True)
     assert d["winner"] == 0 and len(d["moves"]) == 9 and list(d["hist_result"][:2]) == [-1.0, 1.0]
     save("search_ttt_draw", d)
+    # a Go game cut off by max_turn (gameplay.py:46-47: the loop stops once turns > max_turn, i.e. after max_turn + 1
+    # plies) and scored as it stands
+    d = search_trace("go5mt", "go", 5, 5, None, 8, 20, 4, 10, 70, 10 ** 9)
+    assert len(d["moves"]) == 11 and int((d["moves"] == 25).sum()) < 2
+    save("search_go5_maxturn", d)
 
 
 def main():

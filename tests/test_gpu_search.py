@@ -92,7 +92,7 @@ def _selfplay_injected(eng):
         eng.selfplay_finish(pri, v)
 
 
-@pytest.mark.parametrize("name", ["search_ttt_game", "search_reversi_game", "search_go5_game", "search_ttt_draw", "search_reversi6_pass"])
+@pytest.mark.parametrize("name", ["search_ttt_game", "search_reversi_game", "search_go5_game", "search_ttt_draw", "search_reversi6_pass", "search_go5_maxturn"])
 def test_selfplay_machine_full_game(name):
     """Game.start + get_history raw material from the device-side self-play machine, 3 slots
     fed the same draws must all reproduce the reference's game."""
