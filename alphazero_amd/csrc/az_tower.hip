@@ -39,6 +39,11 @@ struct Tower {
     int evs_used;
     double conv_ms;
     unsigned long long conv_launches;
+    // small batches (a game searched alone) are launch-bound: their forward, a fixed chain of about 45 short kernels,
+    // is captured once per (batch size, buffers, stream) and replayed as one graph launch
+    struct Graph { const void *planes; const void *priors, *values, *rows; int B; hipStream_t st; hipGraphExec_t exec; };
+    std::vector<Graph> graphs;
+    bool use_graphs;
 };
 
 static inline bf16_t h_f2bf(float f)
@@ -264,6 +269,7 @@ Tower *tower_create(int H, int W, int O, int num_blocks, int channels, int dtype
     t->H = H; t->W = W; t->HW = H * W; t->PP = (H + 2) * (W + 2); t->O = O; t->NB = num_blocks; t->C = channels;
     t->dtype = dtype; t->maxB = max_batch; t->ready = false;
     t->profile = false; t->evs_used = 0; t->conv_ms = 0; t->conv_launches = 0;
+    t->use_graphs = getenv("AZ_NO_GRAPHS") == nullptr;  // the variable only serves A/B timing
     const size_t C = channels, HW = t->HW;
     t->blob_floats = C * 9 * 17 + C + (size_t)num_blocks * 2 * (C * 9 * C + C) + 3 * C + 3 + 2 * HW * O + O + HW * 256 + 256 + 256 + 1;
     const size_t es = dtype == 1 ? 2 : 4;
@@ -289,6 +295,7 @@ void tower_destroy(Tower *t)
     if (!t) return;
     for (void *p : t->allocs) hipFree(p);
     for (hipEvent_t e : t->evs) hipEventDestroy(e);
+    for (auto &g : t->graphs) hipGraphExecDestroy(g.exec);
     delete t;
 }
 
@@ -443,6 +450,30 @@ int tower_forward(Tower *t, const int8_t *planes_dev, int B, float *priors_dev, 
     if (B < 1 || B > t->maxB) { err = "batch exceeds the tower's activation buffers"; return -1; }
     if (count_dev && !tower_takes_device_count(t, B)) { err = "this tower shape needs the batch size on the host"; return -1; }
     t->evs_used = 0;
+    const bool graphable = t->use_graphs && !t->profile && !count_dev && (size_t)B * t->HW <= SMALL_BATCH_POINTS;
+    if (graphable) {
+        for (auto &g : t->graphs)
+            if (g.B == B && g.planes == planes_dev && g.priors == priors_dev && g.values == values_dev && g.rows == rows_dev && g.st == st) {
+                if (hipGraphLaunch(g.exec, st) == hipSuccess) return 0;
+                break;  // fall back to plain launches below
+            }
+        if (t->graphs.size() < 16 && hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
+            const int crc = t->dtype == 1 ? forward_t<bf16_t>(t, planes_dev, B, priors_dev, values_dev, st, rows_dev, nullptr)
+                                          : forward_t<float>(t, planes_dev, B, priors_dev, values_dev, st, rows_dev, nullptr);
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            const hipError_t e = hipStreamEndCapture(st, &graph);
+            const bool ok = crc == 0 && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) hipGraphDestroy(graph);
+            if (ok && hipGraphLaunch(exec, st) == hipSuccess) {
+                t->graphs.push_back({planes_dev, priors_dev, values_dev, rows_dev, B, st, exec});
+                return 0;
+            }
+            if (exec) hipGraphExecDestroy(exec);
+            (void)hipGetLastError();
+            t->use_graphs = false;  // capture is not available here: plain launches from now on
+        }
+    }
     int rc = t->dtype == 1 ? forward_t<bf16_t>(t, planes_dev, B, priors_dev, values_dev, st, rows_dev, count_dev)
                            : forward_t<float>(t, planes_dev, B, priors_dev, values_dev, st, rows_dev, count_dev);
     if (rc) err = std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError());
