@@ -98,6 +98,7 @@ SIGNATURES = {
     "az_tower_forward": (_I, [_P, _P, _I, _P, _P]),
     "az_tower_forward_dev": (_I, [_P, _P, _I, _P, _P]),
     "az_tower_flops_per_eval": (C.c_double, [_P]),
+    "az_search_run": (_I, [_P, _I]),
     "az_tower_profile": (_I, [_P, _I]),
     "az_tower_leaf_compaction": (_I, [_P, _I]),
     "az_counters_get": (_I, [_P, C.POINTER(AzCounters)]),

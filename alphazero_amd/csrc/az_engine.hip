@@ -714,6 +714,29 @@ extern "C" int az_selfplay_run(az_engine *h, int32_t n_rounds)
     return check_slot_errors(h);
 }
 
+// n_rounds of select -> tower -> finish for the searches begun with az_search_begin, queued on the stream with one
+// synchronisation at the end (the loop of az_search_step_select / az_search_step_finish without a host round trip per
+// playout).  A slot whose search is complete ignores further rounds.
+extern "C" int az_search_run(az_engine *h, int32_t n_rounds)
+{
+    if (!h || n_rounds < 0) return AZ_ERR_ARG;
+    if (!h->tower || !tower_ready(h->tower)) return set_err(h, AZ_ERR_NO_WEIGHTS, "no tower weights loaded");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    for (int r = 0; r < n_rounds; r++) {
+        int rc = launch_select(h);
+        if (rc) return rc;
+        if ((rc = evaluate(h, nullptr, nullptr))) return rc;
+        for (int sub = 0; sub < h->D.K; sub++) {
+            if (h->D.f64) hipLaunchKernelGGL(k_finish<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
+            else hipLaunchKernelGGL(k_finish<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
+        }
+        h->steps++;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return check_slot_errors(h);
+}
+
 extern "C" int az_selfplay_select(az_engine *h, int32_t *n_leaves)
 {
     if (!h) return AZ_ERR_ARG;

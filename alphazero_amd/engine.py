@@ -158,6 +158,9 @@ class Engine:
         fn = self._L.az_search_step_finish_f64 if self.real is np.float64 else self._L.az_search_step_finish
         self._ck(fn(self._h, p.ctypes.data, v.ctypes.data))
 
+    def search_run(self, n_rounds):
+        self._ck(self._L.az_search_run(self._h, int(n_rounds)))
+
     def root_stats(self, slot, side):
         a = np.zeros(self.O, np.int32); n = np.zeros(self.O, np.int32)
         w = np.zeros(self.O, self.real); p = np.zeros(self.O, self.real)

@@ -86,6 +86,7 @@ class MCTSearch(object):
         self._eng_kw = dict(n_slots=1, max_playout=max_playout, rng_replay=leaves_per_round <= 1,
                             leaves_per_round=leaves_per_round, **kw)
         self._multi = leaves_per_round > 1
+        self._K = max(1, int(leaves_per_round))
         self._eng = Engine(**self._eng_kw, **tower_kw)
         self._loaded_version = None
         # Arithmetic of N/W/P follows the evaluator's output type, as NumPy's promotion makes it in the reference:
@@ -124,6 +125,9 @@ class MCTSearch(object):
             if self._loaded_version != self._tower.version:
                 eng.tower_load(self._tower._tower_blob)
                 self._loaded_version = self._tower.version
+            # the rounds the search certainly needs go to the device in one call; the loop picks up what is left
+            # (several leaves per round do not always use a whole round's budget)
+            eng.search_run((self._max_playout + self._K - 1) // self._K + (1 if root_is_leaf else 0))
             while eng.step_select() > 0:
                 eng.step_finish()
             return

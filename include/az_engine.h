@@ -155,6 +155,10 @@ int az_leaf_batch(az_engine *h, int8_t *planes, uint8_t *valid);
  * priors (n_slots,O) and values (n_slots) float32 host arrays, in the evaluator's
  * (transformed) index order; both NULL = run the tower on the leaf batch. */
 int az_search_step_finish(az_engine *h, const float *priors, const float *values);
+/* n_rounds of (select, tower, finish) queued on the engine's stream with one synchronisation at the end: the reference's
+ * `for _ in range(max_playout): self._playout(...)` (search/mcts.py:295-296) without a host round trip per playout.
+ * Needs tower weights; slots whose search is complete ignore the extra rounds. */
+int az_search_run(az_engine *h, int32_t n_rounds);
 /* root children in insertion order (MCTreeNode._children of _root): returns count */
 int az_search_root_stats(az_engine *h, int32_t slot, int32_t side, int32_t *actions, int32_t *visits,
                          float *total_value, float *prior, int32_t *root_visits);

@@ -267,3 +267,33 @@ def test_selfplay_with_several_leaves_per_round():
         assert np.all(tr["visits"].sum(axis=1) >= P) and tr["winner"] in (-1, 0, 1)
         assert np.all(tr["visits"][0:2].sum(axis=1) == P)   # fresh roots: exactly the budget
     eng.close()
+
+
+@pytest.mark.parametrize("K", [1, 4])
+def test_queued_search_rounds_equal_the_stepwise_loop(K):
+    """az_search_run (rounds queued on the device, one synchronisation) against the select / finish loop with a host
+    round trip per playout: same kernels in the same order, so the trees must be identical; extra rounds after the
+    budget is spent must change nothing."""
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.network.model import fold_to_blob, random_net
+    H, P = 9, 40
+    blob = fold_to_blob(random_net(H, H, 82, 1, 128, seed=2, perturb_bn=True))
+    stats = []
+    for queued in (True, False):
+        eng = Engine("go", H, H, n_slots=3, max_playout=P, transform_types=8, seed=17, num_blocks=1, channels=128,
+                     tower_dtype="fp32", leaves_per_round=K)
+        eng.tower_load(blob)
+        eng.do_move([0, 1, 2], [40, 41, 30])
+        eng.search_begin([0, 1, 2], [1, 1, 0], [1, 0, 1])
+        if queued:
+            eng.search_run((P + K - 1) // K + 1)      # root expansion + the playout budget
+            eng.search_run(3)                         # nothing left to do: no-ops
+        while eng.step_select() > 0:
+            eng.step_finish()
+        stats.append([eng.root_stats(s, sd) for s, sd in ((0, 1), (1, 1), (2, 0))])
+        eng.close()
+    for a, b in zip(*stats):
+        assert a[4] == b[4] == P + 1
+        for x, y in zip(a[:4], b[:4]):
+            assert np.array_equal(x, y)
+        assert a[1].sum() == P
