@@ -186,47 +186,111 @@ __device__ __forceinline__ void append_move(PS &s, int a)
 // Go: chain labels (min cell index of the chain) and liberty counts
 // ---------------------------------------------------------------------------
 
-__device__ void go_label(const Geo &G, WLds &L, const int8_t *b)
+// The cells a lane owns (lane, lane + 64, ...) with their neighbourhood, gathered once per labelling so that the loops
+// below are straight-line code: every LDS read is unconditional (a missing neighbour reads the cell itself) and the
+// reads of all 6 cells are in flight together instead of one dependent, branch-guarded read after another.
+//   info bits 0-3: neighbour (x-1, x+1, y-1, y+1) exists; bit 4: the cell is on the board;
+//   bits 8-9: colour code of the cell, bits 10-17: colour codes of the four neighbours (0 empty, 1 black, 3 white)
+struct GoCells {
+    int idx[AZ_NJ];
+    unsigned info[AZ_NJ];
+};
+__device__ __forceinline__ int go_nb(const GoCells &gc, int j, int q, int W)
 {
-    const int lane = lane_id();
+    const int d = q == 0 ? -W : q == 1 ? W : q == 2 ? -1 : 1;
+    return gc.idx[j] + (((gc.info[j] >> q) & 1u) ? d : 0);
+}
+__device__ __forceinline__ int go_col(const GoCells &gc, int j) { return (int)((gc.info[j] >> 8) & 3u); }
+__device__ __forceinline__ int go_ncol(const GoCells &gc, int j, int q) { return (int)((gc.info[j] >> (10 + 2 * q)) & 3u); }
+
+__device__ __forceinline__ void go_cells(const Geo &G, const int8_t *b, GoCells &gc)
+{
+    int lane = lane_id();
+    // everything below derives from the lane number and the board geometry only, so a caller that labels inside a loop
+    // would have all of it hoisted out and kept in registers (some 200 of them); the empty asm makes it per-call work
+    asm volatile("" : "+v"(lane));
     const int W = G.W, H = G.H, NC = G.NC;
-    for (int i = lane; i < NC; i += AZ_WAVE) {
-        L.label[i] = (int16_t)i;
-        L.libs[i] = 0;
+#pragma unroll
+    for (int j = 0; j < AZ_NJ; j++) {
+        const int i = lane + j * AZ_WAVE;
+        const bool on = i < NC;
+        const int ii = on ? i : 0;
+        const int x = ii / W, y = ii - x * W;
+        gc.idx[j] = ii;
+        gc.info[j] = (on ? 16u : 0u) | (on && x > 0 ? 1u : 0u) | (on && x + 1 < H ? 2u : 0u) | (on && y > 0 ? 4u : 0u) |
+                     (on && y + 1 < W ? 8u : 0u);
     }
+#pragma unroll
+    for (int j = 0; j < AZ_NJ; j++) {
+        unsigned cc = (unsigned)b[gc.idx[j]] & 3u;
+        if (!(gc.info[j] & 16u)) cc = 0;
+        unsigned inf = gc.info[j] | (cc << 8);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned cn = (unsigned)b[go_nb(gc, j, q, W)] & 3u;
+            inf |= (((gc.info[j] >> q) & 1u) ? cn : 0u) << (10 + 2 * q);
+        }
+        gc.info[j] = inf;
+    }
+}
+
+// chain labels and liberty counts of the board described by gc (go_cells of the same board)
+__device__ __forceinline__ void go_label(const Geo &G, WLds &L, const GoCells &gc)
+{
+    const int W = G.W;
+#pragma unroll
+    for (int j = 0; j < AZ_NJ; j++)
+        if (gc.info[j] & 16u) {
+            L.label[gc.idx[j]] = (int16_t)gc.idx[j];
+            L.libs[gc.idx[j]] = 0;
+        }
     WSYNC();
     for (;;) {
         int changed = 0;
-        for (int i = lane; i < NC; i += AZ_WAVE) {
-            int c = b[i];
-            if (c == 0) continue;
-            int x = i / W, y = i - x * W;
-            int m = L.label[i], m0 = m;
-            if (x > 0 && b[i - W] == c) m = min(m, (int)L.label[i - W]);
-            if (x + 1 < H && b[i + W] == c) m = min(m, (int)L.label[i + W]);
-            if (y > 0 && b[i - 1] == c) m = min(m, (int)L.label[i - 1]);
-            if (y + 1 < W && b[i + 1] == c) m = min(m, (int)L.label[i + 1]);
-            m = min(m, (int)L.label[m]);
-            if (m < m0) { L.label[i] = (int16_t)m; changed = 1; }
+        int m0[AZ_NJ], m[AZ_NJ];
+#pragma unroll
+        for (int j = 0; j < AZ_NJ; j++) {
+            const int c = go_col(gc, j);
+            m0[j] = L.label[gc.idx[j]];
+            int mm = m0[j];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int l = L.label[go_nb(gc, j, q, W)];
+                if (((gc.info[j] >> q) & 1u) && c != 0 && go_ncol(gc, j, q) == c) mm = min(mm, l);
+            }
+            m[j] = mm;
         }
+#pragma unroll
+        for (int j = 0; j < AZ_NJ; j++) m[j] = min(m[j], (int)L.label[m[j]]);
+#pragma unroll
+        for (int j = 0; j < AZ_NJ; j++)
+            if (go_col(gc, j) != 0 && m[j] < m0[j]) { L.label[gc.idx[j]] = (int16_t)m[j]; changed = 1; }
         WSYNC();
         if (!__any(changed)) break;
     }
     // liberties: every empty point adds one to each distinct neighbouring chain
-    for (int i = lane; i < NC; i += AZ_WAVE) {
-        if (b[i] != 0) continue;
-        int x = i / W, y = i - x * W;
-        int l0 = -1, l1 = -1, l2 = -1, l3 = -1;
-        if (x > 0 && b[i - W] != 0) l0 = L.label[i - W];
-        if (x + 1 < H && b[i + W] != 0) l1 = L.label[i + W];
-        if (y > 0 && b[i - 1] != 0) l2 = L.label[i - 1];
-        if (y + 1 < W && b[i + 1] != 0) l3 = L.label[i + 1];
-        if (l0 >= 0) atomicAdd(&L.libs[l0], 1);
-        if (l1 >= 0 && l1 != l0) atomicAdd(&L.libs[l1], 1);
-        if (l2 >= 0 && l2 != l0 && l2 != l1) atomicAdd(&L.libs[l2], 1);
-        if (l3 >= 0 && l3 != l0 && l3 != l1 && l3 != l2) atomicAdd(&L.libs[l3], 1);
+#pragma unroll
+    for (int j = 0; j < AZ_NJ; j++) {
+        int lq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int l = L.label[go_nb(gc, j, q, W)];
+            const bool stone = ((gc.info[j] >> q) & 1u) && go_ncol(gc, j, q) != 0;
+            lq[q] = (gc.info[j] & 16u) && go_col(gc, j) == 0 && stone ? l : -1;
+        }
+        if (lq[0] >= 0) atomicAdd(&L.libs[lq[0]], 1);
+        if (lq[1] >= 0 && lq[1] != lq[0]) atomicAdd(&L.libs[lq[1]], 1);
+        if (lq[2] >= 0 && lq[2] != lq[0] && lq[2] != lq[1]) atomicAdd(&L.libs[lq[2]], 1);
+        if (lq[3] >= 0 && lq[3] != lq[0] && lq[3] != lq[1] && lq[3] != lq[2]) atomicAdd(&L.libs[lq[3]], 1);
     }
     WSYNC();
+}
+
+__device__ __forceinline__ void go_label(const Geo &G, WLds &L, const int8_t *b)
+{
+    GoCells gc;
+    go_cells(G, b, gc);
+    go_label(G, L, gc);
 }
 
 __device__ __forceinline__ int go_chain_libs(WLds &L, int cell) { return L.libs[L.label[cell]]; }
@@ -242,28 +306,42 @@ __device__ int dev_legal_mask(const Geo &G, WLds &L, const PS &s)
     const int8_t *b = cur_board(L, s);
     int count = 0;
     if (G.game == G_GO) {
-        go_label(G, L, b);
-        for (int i0 = 0; i0 < NC; i0 += AZ_WAVE) {
-            int i = i0 + lane;
-            int legal = 0;
-            if (i < NC && b[i] == 0) {
-                int x = i / W, y = i - x * W;
-                int nb[4], n = 0;
-                if (x > 0) nb[n++] = i - W;
-                if (x + 1 < H) nb[n++] = i + W;
-                if (y > 0) nb[n++] = i - 1;
-                if (y + 1 < W) nb[n++] = i + 1;
-                for (int q = 0; q < n; q++) {
-                    int r = nb[q], c = b[r];
-                    if (c == 0) legal = 1;
-                    else {
-                        int lb = go_chain_libs(L, r);
-                        if (c == s.cur && lb >= 2) legal = 1;
-                        if (c == -s.cur && lb == 1) legal = 1;
+        GoCells gc;
+        go_cells(G, b, gc);
+        const int me = s.cur & 3, opp = (-s.cur) & 3;
+        // an empty point next to an empty point is legal whatever the chains look like; only points with every
+        // neighbour occupied need liberty counts, and a board without such points (most of an opening) is not labelled
+        int open[AZ_NJ], need = 0;
+#pragma unroll
+        for (int j = 0; j < AZ_NJ; j++) {
+            const bool empty = (gc.info[j] & 16u) && go_col(gc, j) == 0;
+            bool o = false;
+#pragma unroll
+            for (int q = 0; q < 4; q++) o = o || (((gc.info[j] >> q) & 1u) && go_ncol(gc, j, q) == 0);
+            open[j] = empty && o;
+            need |= empty && !o;
+        }
+        const bool labelled = __any(need);
+        if (labelled) go_label(G, L, gc);
+#pragma unroll
+        for (int j = 0; j < AZ_NJ; j++) {
+            const int i = lane + j * AZ_WAVE;
+            int legal = open[j];
+            if (labelled) {
+                int lb[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) lb[q] = L.libs[L.label[go_nb(gc, j, q, W)]];
+                if ((gc.info[j] & 16u) && go_col(gc, j) == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (!((gc.info[j] >> q) & 1u)) continue;
+                        const int c = go_ncol(gc, j, q);
+                        if (c == me && lb[q] >= 2) legal = 1;
+                        if (c == opp && lb[q] == 1) legal = 1;
                     }
                 }
-                if (i == s.ko) legal = 0;
             }
+            if (i == s.ko) legal = 0;
             if (i < NC) L.mask[i] = (uint8_t)legal;
             count += __popcll(__ballot(legal));
         }
@@ -315,16 +393,21 @@ __device__ void dev_do_move(const Geo &G, WLds &L, PS &s, int a)
         push_history(L, s);
         int8_t *b = cur_board(L, s);
         if (a != NC) {
-            if (lane == 0) b[a] = (int8_t)color;
-            WSYNC();
-            go_label(G, L, b);
-            // ko bookkeeping needs the pre-capture neighbourhood of `a`
             int x = a / W, y = a - x * W;
             int nb[4], n = 0;
             if (x > 0) nb[n++] = a - W;
             if (x + 1 < H) nb[n++] = a + W;
             if (y > 0) nb[n++] = a - 1;
             if (y + 1 < W) nb[n++] = a + 1;
+            int hostile = 0;
+            for (int q = 0; q < n; q++) hostile |= b[nb[q]] == -color;
+            if (lane == 0) b[a] = (int8_t)color;
+            WSYNC();
+            // a stone that touches no opposing stone captures nothing and marks no ko (the move is known to be legal,
+            // so it is no suicide either): the chains only have to be labelled for a contact move
+            if (hostile) {
+            go_label(G, L, b);
+            // ko bookkeeping needs the pre-capture neighbourhood of `a`
             int friendly = 0, empty = 0, first = -1;
             for (int q = 0; q < n; q++) {
                 int r = nb[q], c = b[r];
@@ -360,6 +443,7 @@ __device__ void dev_do_move(const Geo &G, WLds &L, PS &s, int a)
             WSYNC();
             if (color == 1) s.pris_w += removed; else s.pris_b += removed;
             s.ko = ko;
+            }
         } else {
             if (color == 1) s.passes_b++; else s.passes_w++;
         }

@@ -1020,3 +1020,17 @@ extern "C" int az_sync(az_engine *h)
     HIPCHK(hipStreamSynchronize(h->stream));
     return AZ_OK;
 }
+
+#ifdef AZ_STAMP_SELECT
+// development build only (tools/select_stamps.py): accumulated phase cycles of k_select's block 0; reading resets them
+extern "C" int az_debug_select_stamps(az_engine *h, unsigned long long *out16)
+{
+    if (!h || !out16) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sel_stamps), 16 * sizeof(unsigned long long)));
+    unsigned long long z[16] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sel_stamps), z, sizeof z));
+    return AZ_OK;
+}
+#endif

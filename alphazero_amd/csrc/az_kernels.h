@@ -98,6 +98,14 @@ __device__ void apply_noise(const Dev &D, int g, int t)
 // (search/mcts.py:173-217, :261-280)
 // ---------------------------------------------------------------------------
 
+#ifdef AZ_STAMP_SELECT
+// development build only: shader-clock stamps of one wavefront's phases in k_select (block 0, lane 0)
+__device__ unsigned long long g_sel_stamps[16];
+#define SEL_STAMP(i) do { if (blockIdx.x == 0 && lane == 0) g_sel_stamps[i] += __builtin_amdgcn_s_memtime() - t_prev; t_prev = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SEL_STAMP(i) do {} while (0)
+#endif
+
 template <typename R>
 __global__ __launch_bounds__(64) void k_select(Dev D, int sub)
 {
@@ -107,6 +115,9 @@ __global__ __launch_bounds__(64) void k_select(Dev D, int sub)
     const int g = blockIdx.x;
     const int li = sub * D.G + g;  // row of this sub-round's leaf
     const int lane = lane_id();
+#ifdef AZ_STAMP_SELECT
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
     const Geo G = D.geo;
     int phase = D.phase[g];
     if (lane == 0) D.leaf_valid[li] = 0;
@@ -126,6 +137,7 @@ __global__ __launch_bounds__(64) void k_select(Dev D, int sub)
     int root_expand = 0;
     int rootN = D.rootN[t];
     WSYNC();
+    SEL_STAMP(0);  // state load
     if (phase == PH_NEED_START) {
         rootN += 1;  // self._root.visit(), mcts.py:261
         if (D.rootBlock[t] < 0) {
@@ -146,6 +158,7 @@ __global__ __launch_bounds__(64) void k_select(Dev D, int sub)
         rootN += 1;  // node.visit() of the root inside _playout
         int blk = D.rootBlock[t];
         int parentN = rootN;
+        SEL_STAMP(1);  // search start / noise
         while (blk >= 0) {
             int start = D.bStart[bb + blk], n = D.bCount[bb + blk];
             // Q+U in the evaluator's precision, left to right as mcts.py:88-90; first maximum wins
@@ -178,7 +191,9 @@ __global__ __launch_bounds__(64) void k_select(Dev D, int sub)
             }
             depth++;
             int a = D.eAct[tb + e];
+            SEL_STAMP(2);  // child scan + arg-max
             dev_do_move(G, L, s, a);
+            SEL_STAMP(3);  // rule move
             int N = D.eN[tb + e] + 1;  // child.visit()
             WSYNC();
             if (lane == 0) {
@@ -188,6 +203,7 @@ __global__ __launch_bounds__(64) void k_select(Dev D, int sub)
             node = e; node_block = blk;
             parentN = N;
             blk = D.eChild[tb + e];
+            SEL_STAMP(4);  // visit store + child pointer
         }
     }
     if (lane == 0) {
@@ -197,14 +213,18 @@ __global__ __launch_bounds__(64) void k_select(Dev D, int sub)
 
     // leaf: transform id, legality on the un-transformed state, evaluator input
     int tid = D.transform_on ? rng_tid(D, g) : 0;
+    SEL_STAMP(5);
     int nlegal = dev_legal_mask(G, L, s);
+    SEL_STAMP(6);  // legal mask
     uint8_t *gm = D.leaf_mask + (size_t)li * AZ_OP;
     for (int i = lane; i < AZ_OP / 4; i += AZ_WAVE)
         reinterpret_cast<int *>(gm)[i] = reinterpret_cast<int *>(L.mask)[i];
     int terminal = (nlegal == 0) || s.is_end;
     int win = 0;
     if (terminal && !root_expand) win = dev_winner(G, L, s);
+    SEL_STAMP(7);  // mask store, winner
     dev_features(G, L, s, tid, D.planes + (size_t)li * 17 * G.NC);
+    SEL_STAMP(8);  // feature planes
     if (lane == 0) {
         D.leaf_valid[li] = 1;
         D.leaf_node[li] = node;
