@@ -152,6 +152,9 @@ __global__ __launch_bounds__(64) void k_select(Dev D, int sub)
             }
         }
     }
+    // the playout's transform id (one draw per playout, mcts.py:208) is fetched here so that the dependent loads of the
+    // replay stream overlap the descent; it is used at the leaf
+    const int tid = D.transform_on ? rng_tid(D, g) : 0;
     int node = NODE_ROOT, node_block = -1, depth = 0;
     unsigned long long levels = 0, scanned = 0;
     if (!root_expand) {
@@ -161,20 +164,34 @@ __global__ __launch_bounds__(64) void k_select(Dev D, int sub)
         SEL_STAMP(1);  // search start / noise
         while (blk >= 0) {
             int start = D.bStart[bb + blk], n = D.bCount[bb + blk];
-            // Q+U in the evaluator's precision, left to right as mcts.py:88-90; first maximum wins
+            // Q+U in the evaluator's precision, left to right as mcts.py:88-90; first maximum wins.  A node has at most
+            // AZ_NJ * 64 children: all their statistics are requested before any is used (one memory latency per level,
+            // not one per 64 children); a slot past the end re-reads the last child and is ignored.
             R sq = (R)sqrt((double)parentN);
+            int cN[AZ_NJ];
+            R cW[AZ_NJ], cP[AZ_NJ];
+#pragma unroll
+            for (int j = 0; j < AZ_NJ; j++) {
+                const size_t ci = tb + start + min(lane + j * AZ_WAVE, n - 1);
+                cN[j] = D.eN[ci]; cW[j] = eW[ci]; cP[j] = eP[ci];
+            }
             R bv = -INFINITY;
-            int bi = 0x7fffffff;
-            for (int c = lane; c < n; c += AZ_WAVE) {
-                int N = D.eN[tb + start + c];
-                R Wv = eW[tb + start + c], P = eP[tb + start + c];
-                R u = (R)5.0 * P;
+            int bi = 0x7fffffff, bN = cN[0];
+#pragma unroll
+            for (int j = 0; j < AZ_NJ; j++) {
+                const int c = lane + j * AZ_WAVE;
+                const int N = cN[j];
+                R u = (R)5.0 * cP[j];
                 u = u * sq;
                 u = u / ((R)1.0 + (R)N);
-                R q = N == 0 ? (R)0.0 : Wv / (R)N;
+                R q = N == 0 ? (R)0.0 : cW[j] / (R)N;
                 R v = q + u;
-                if (v > bv) { bv = v; bi = c; }
+                if (c < n && v > bv) { bv = v; bi = c; bN = N; }
             }
+            // the action and the child block of this lane's own best candidate are fetched while the lanes compare
+            const size_t mine = tb + start + (bi == 0x7fffffff ? min(lane, n - 1) : bi);
+            if (bi == 0x7fffffff) bN = cN[0];
+            const int myAct = D.eAct[mine], myChild = D.eChild[mine];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 R ov = __shfl_xor(bv, o, 64);
@@ -190,11 +207,12 @@ __global__ __launch_bounds__(64) void k_select(Dev D, int sub)
                 D.path_player[(size_t)li * D.MAXD + depth] = (int8_t)s.cur;
             }
             depth++;
-            int a = D.eAct[tb + e];
+            const int wl = bi & (AZ_WAVE - 1);  // child c sits in lane c % 64
+            int a = __shfl(myAct, wl, 64);
             SEL_STAMP(2);  // child scan + arg-max
             dev_do_move(G, L, s, a);
             SEL_STAMP(3);  // rule move
-            int N = D.eN[tb + e] + 1;  // child.visit()
+            int N = __shfl(bN, wl, 64) + 1;  // child.visit()
             WSYNC();
             if (lane == 0) {
                 D.eN[tb + e] = N;
@@ -202,7 +220,7 @@ __global__ __launch_bounds__(64) void k_select(Dev D, int sub)
             }
             node = e; node_block = blk;
             parentN = N;
-            blk = D.eChild[tb + e];
+            blk = __shfl(myChild, wl, 64);
             SEL_STAMP(4);  // visit store + child pointer
         }
     }
@@ -212,7 +230,6 @@ __global__ __launch_bounds__(64) void k_select(Dev D, int sub)
     }
 
     // leaf: transform id, legality on the un-transformed state, evaluator input
-    int tid = D.transform_on ? rng_tid(D, g) : 0;
     SEL_STAMP(5);
     int nlegal = dev_legal_mask(G, L, s);
     SEL_STAMP(6);  // legal mask
