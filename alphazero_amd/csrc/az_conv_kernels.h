@@ -298,17 +298,19 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16(const bf16_t *__restr
 
 // bias -> bf16 -> per-wave LDS transpose -> 16-byte rows (+ residual, ReLU) -> NHWC stores.
 // All LDS reads of the K loop must be complete (barrier) before the call.
-template <bool RESID>
-__device__ __forceinline__ void conv_epilogue(unsigned char *smem, const int *rowoff, f32x4 (&acc)[4][8], const float *__restrict__ bias,
+template <bool RESID, int NI>
+__device__ __forceinline__ void conv_epilogue(unsigned char *smem, const int *rowoff, f32x4 (&acc)[NI][8], const float *__restrict__ bias,
                                               const bf16_t *__restrict__ R, bf16_t *__restrict__ Y, int M, int m0, int wave, int lane,
-                                              int wr, int wc)
+                                              int wr, int cbase)
 {
     constexpr int C = 256;
-    // ---- epilogue (as in k_conv3x3_c256_bf16)
+    constexpr int CPR = NI * 2;       // 16-byte pieces (8 channels) in one point's row of this wave
+    constexpr int RPP = 64 / CPR;     // points the wave stores per pass
+    constexpr int NPASS = 128 / RPP;
     unsigned char *reg = smem + wave * 18432;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const float4 b4 = *reinterpret_cast<const float4 *>(bias + wc * 64 + i * 16 + (lane >> 4) * 4);
+    for (int i = 0; i < NI; i++) {
+        const float4 b4 = *reinterpret_cast<const float4 *>(bias + cbase + i * 16 + (lane >> 4) * 4);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const f32x4 a = acc[i][j];
@@ -318,24 +320,24 @@ __device__ __forceinline__ void conv_epilogue(unsigned char *smem, const int *ro
             *reinterpret_cast<uint2 *>(reg + (j * 16 + (lane & 15)) * 144 + (i * 16 + (lane >> 4) * 4) * 2) = pk;
         }
     }
-    const int erow = lane >> 3, echunk = lane & 7;
-    uint4 rres[16];
+    const int erow = lane / CPR, echunk = lane % CPR;
+    uint4 rres[NPASS];
     if (RESID) {
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
-            const int trow = wr * 128 + it * 8 + erow;
+        for (int it = 0; it < NPASS; it++) {
+            const int trow = wr * 128 + it * RPP + erow;
             rres[it] = make_uint4(0, 0, 0, 0);
-            if (m0 + trow < M) rres[it] = *reinterpret_cast<const uint4 *>(R + (size_t)rowoff[trow] * C + wc * 64 + echunk * 8);
+            if (m0 + trow < M) rres[it] = *reinterpret_cast<const uint4 *>(R + (size_t)rowoff[trow] * C + cbase + echunk * 8);
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 16; it++) {
-        const int row = it * 8 + erow;
+    for (int it = 0; it < NPASS; it++) {
+        const int row = it * RPP + erow;
         const int trow = wr * 128 + row;
         if (m0 + trow < M) {
             uint4 v = *reinterpret_cast<const uint4 *>(reg + row * 144 + echunk * 16);
-            const size_t o = (size_t)rowoff[trow] * C + wc * 64 + echunk * 8;
+            const size_t o = (size_t)rowoff[trow] * C + cbase + echunk * 8;
             unsigned vv[4] = {v.x, v.y, v.z, v.w};
             unsigned rr[4] = {0, 0, 0, 0};
             if (RESID) { rr[0] = rres[it].x; rr[1] = rres[it].y; rr[2] = rres[it].z; rr[3] = rres[it].w; }
@@ -459,13 +461,21 @@ __device__ __forceinline__ int xcd_tile(int wg, int nwg)
 #endif
 }
 
-template <bool RESID, int NSP, int CIN = 256>
+// CW = output channels per wave (64, 32 or 16): a workgroup covers 4 * CW channels of its 256 points and blockIdx.y
+// picks which, so a batch with few tiles can still occupy the chip (each workgroup then re-reads the activation slab
+// but only its share of the weights).
+template <bool RESID, int NSP, int CIN = 256, int CW = 64>
 __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
                                                                 const float *__restrict__ bias, const bf16_t *__restrict__ R,
                                                                 bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP, int npos,
                                                                 const int32_t *__restrict__ cnt)
 {
     constexpr int C = 256, NCC = CIN / 32, SLAB_BYTES = NSP * 128 * 64;  // C output channels, NCC 32-channel input chunks
+    constexpr int NI = CW / 16;            // 16-channel MFMA blocks per wave
+    constexpr int WROWS = 4 * CW;          // weight rows (output channels) of this workgroup
+    constexpr int WB = CW == 64 ? 2 : 1;   // LDS-DMA loads per wave and weight batch (16 rows each)
+    static_assert(CW == 64 || CW == 32 || CW == 16, "channels per wave");
+    const int cout0 = blockIdx.y * WROWS;
     // with the number of boards kept on the device the grid covers the capacity M / HW: the first ceil(M / 256)
     // workgroups (still round-robin over the XCDs) share the live tiles, the others have nothing to do
     int nwg = gridDim.x;
@@ -496,11 +506,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
     if (tid < 256) srow[tid] = (rowoff[tid] - pbase) * 64;  // byte offset of the pixel's own row + (W2+1) rows
     // weight fill mapping: wave w fills rows w*32 + q*16 + (lane>>2), slot lane&3
     const int frow = lane >> 2, fslot = lane & 3;
-    int woff[2];
+    int woff[WB];
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int r = wave * 32 + q * 16 + frow;
-        woff[q] = r * 9 * CIN + ((fslot ^ (((r >> 2) & 1) << 1)) << 3);
+    for (int q = 0; q < WB; q++) {
+        // CW = 16 has 64 rows for 8 waves: waves 4-7 repeat the rows of waves 0-3 (same bytes to the same place), which
+        // keeps the number of loads per wave, and with it the vmcnt bookkeeping, the same for every wave
+        const int r = (wave * 16 * WB + q * 16 + frow) % WROWS;
+        woff[q] = (cout0 + r) * 9 * CIN + ((fslot ^ (((r >> 2) & 1) << 1)) << 3);
     }
     // slab fill mapping: wave w fills pieces w + 8*i (16 rows each)
     int soff[NSP];
@@ -510,19 +522,19 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
         const int pos = min(pbase + sr, npos - 1);
         soff[i] = pos * CIN + ((fslot ^ (((sr >> 2) & 1) << 1)) << 3);
     }
-    unsigned char *const wfill = smem + (wave * 32) * 64;
-    const int wrdo = (wc * 64 + (lane & 15)) * 64 + ((((lane >> 4)) ^ ((((lane & 15) >> 2) & 1) << 1)) << 4);
+    unsigned char *const wfill = smem + ((wave * 16 * WB) % WROWS) * 64;
+    const int wrdo = (wc * CW + (lane & 15)) * 64 + ((((lane >> 4)) ^ ((((lane & 15) >> 2) & 1) << 1)) << 4);
     __syncthreads();
     int xrow[8];  // byte offset of each fragment's pixel row inside the slab (+ k-chunk), before the tap shift
 #pragma unroll
     for (int j = 0; j < 8; j++) xrow[j] = srow[wr * 128 + j * 16 + (lane & 15)] + ((lane >> 4) << 4);
 
-    f32x4 acc[4][8];
+    f32x4 acc[NI][8];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 wf[4], xf[8];
+    bf16x8 wf[NI], xf[8];
 
     int opaque0 = 0;  // re-defined by an empty asm every chunk so that per-tap addresses are not hoisted into VGPRs
     // (cc, tap) = 32-channel chunk and filter tap of half-step h = 9*cc + tap; ring slot of its weights = h & 3
@@ -533,7 +545,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
         const int wofs = tap * CIN + cc * 32 + opaque0;
         unsigned char *dst = wfill + ((cc + tap) & 3) * 16384;
 #pragma unroll
-        for (int q = 0; q < 2; q++) glds16(Wt + woff[q] + wofs, dst + q * 1024);
+        for (int q = 0; q < WB; q++) glds16(Wt + woff[q] + wofs, dst + q * 1024);
     };
     auto issue_slab = [&](int cc) {
 #ifdef ABL_NODMA
@@ -552,7 +564,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
         const unsigned char *wb = smem + ((cc + tap) & 3) * 16384 + wrdo;
         const unsigned char *sb = smem + V5_SLAB0 + (cc & 1) * SLAB_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; i++) wf[i] = *reinterpret_cast<const bf16x8 *>(wb + i * 1024);
+        for (int i = 0; i < NI; i++) wf[i] = *reinterpret_cast<const bf16x8 *>(wb + i * 1024);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int a = xrow[j] + tshift;  // row*64 + chunk*16
@@ -561,7 +573,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
     };
     auto mfma_rows = [&](int i0, int i1) {
 #ifdef ABL_NOMFMA
-        asm volatile("" :: "v"(wf[0]), "v"(xf[0]), "v"(wf[3]), "v"(xf[7]));
+        asm volatile("" :: "v"(wf[0]), "v"(xf[0]), "v"(wf[NI - 1]), "v"(xf[7]));
         return;
 #endif
 #pragma unroll
@@ -602,25 +614,25 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
         else if (cc < NCC - 1) issue_w(cc + 1, tn - 9);
         else if (NPF != 0 && tap == 6) prefetch_resid();
         __builtin_amdgcn_sched_barrier(0);
-        mfma_rows(1, 2);
+        mfma_rows(1, NI < 2 ? NI : 2);
         __builtin_amdgcn_sched_barrier(0);
         if (tap == slab_tap && cc < NCC - 1) issue_slab(cc + 1);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_rows(2, 4);
+        mfma_rows(NI < 2 ? NI : 2, NI);
         __builtin_amdgcn_s_setprio(0);
     };
     // vmcnt bookkeeping (per wave, in issue order): before half-step h+1 is read its weights must have
     // landed; `ahead` younger weight batches (2 glds each) may stay in flight, plus the NSP slab pieces
     // while they are younger than W(h+1).
     auto retire_g0 = [&](int cc, int tap) {  // end of group 0's MFMA interval of (cc, tap); issued up to W(h+3)
-        if (cc < NCC - 1) { if (tap < 3) wait_vmcnt<4 + NSP>(); else wait_vmcnt<4>(); }
-        else if (tap <= 5) wait_vmcnt<4>();
-        else if (tap == 6) wait_vmcnt<2 + NPF>();
+        if (cc < NCC - 1) { if (tap < 3) wait_vmcnt<2 * WB + NSP>(); else wait_vmcnt<2 * WB>(); }
+        else if (tap <= 5) wait_vmcnt<2 * WB>();
+        else if (tap == 6) wait_vmcnt<WB + NPF>();
         else wait_vmcnt<NPF>();
     };
     auto retire_g1 = [&](int cc, int tap) {  // end of group 1's read interval of (cc, tap); issued up to W(h+2)
-        if (cc < NCC - 1) { if (tap == 1 || tap == 2) wait_vmcnt<2 + NSP>(); else wait_vmcnt<2>(); }
-        else if (tap <= 6) wait_vmcnt<2>();
+        if (cc < NCC - 1) { if (tap == 1 || tap == 2) wait_vmcnt<WB + NSP>(); else wait_vmcnt<WB>(); }
+        else if (tap <= 6) wait_vmcnt<WB>();
         else wait_vmcnt<NPF>();  // the prefetch was issued in the MFMA interval of (7, 6), one interval earlier
     };
 #define SB() __builtin_amdgcn_sched_barrier(0)
@@ -631,7 +643,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
 #endif
 
     issue_slab(0); issue_w(0, 0); issue_w(0, 1); issue_w(0, 2);
-    wait_vmcnt<4>();
+    wait_vmcnt<2 * WB>();
     PP_BAR();
 #ifdef STAMP
     if (blockIdx.x == 300 && threadIdx.x == 0) { g_stamps[0][500] = __builtin_amdgcn_s_memrealtime(); g_stamps[0][502] = __builtin_amdgcn_s_memtime(); }
@@ -684,9 +696,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
 #endif
     if (kLdsEpilogue) {
         __syncthreads();
-        conv_epilogue<RESID>(smem, rowoff, acc, bias, R, Y, M, m0, wave, lane, wr, wc);
+        conv_epilogue<RESID, NI>(smem, rowoff, acc, bias, R, Y, M, m0, wave, lane, wr, cout0 + wc * CW);
     } else {
+#if defined(EPI_DIRECT)
         conv_epilogue_direct<RESID>(rowoff, acc, bias, R, Y, M, m0, lane, wr, wc, rpre);
+#endif
     }
 }
 
@@ -708,20 +722,44 @@ static inline int conv_slab_span(int HW, int Wd, int PP)
 static inline bool launch_v5_stem(const bf16_t *X, const bf16_t *Wt, const float *bias, bf16_t *Y, int M, int HW, int Wd, int PP,
                                   hipStream_t st = 0, const int32_t *cnt = nullptr);
 
+// How many ways the 256 output channels of a tile are split over workgroups (blockIdx.y): with fewer tiles than
+// compute units a whole-tile workgroup leaves most of the chip idle, so the tiles are cut along the channel axis.
+// A workgroup's time is set mostly by its 72 dependent K steps, not by its MFMAs (whole tile 52 us, half 41, quarter 37
+// on 19x19 boards), so splitting pays only while all pieces run at once.
+static inline int conv_channel_split(int M, int compute_units = 256)
+{
+    const int tiles = (M + 255) / 256;
+    if (tiles * 4 <= compute_units) return 4;
+    if (tiles * 2 <= compute_units) return 2;
+    return 1;
+}
+
+template <bool RESID, int NSP>
+static inline void launch_v5_cw(int cs, dim3 g, dim3 blk, hipStream_t st, const bf16_t *X, const bf16_t *Wt, const float *bias,
+                                const bf16_t *R, bf16_t *Y, int M, int HW, int Wd, int PP, int npos, const int32_t *cnt)
+{
+    g.y = cs;
+    if (cs == 4) hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<RESID, NSP, 256, 16>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+    else if (cs == 2) hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<RESID, NSP, 256, 32>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+    else hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<RESID, NSP, 256, 64>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+}
+
+// cs: channel split (1, 2 or 4), 0 = choose from the batch size
 static inline bool launch_v5(const bf16_t *X, const bf16_t *Wt, const float *bias, const bf16_t *R, bf16_t *Y, int M, int HW, int Wd,
-                             int PP, hipStream_t st = 0, const int32_t *cnt = nullptr)
+                             int PP, hipStream_t st = 0, const int32_t *cnt = nullptr, int cs = 0)
 {
     const int span = conv_slab_span(HW, Wd, PP);
     const int npos = (M / HW) * PP;
     dim3 g((M + 255) / 256), blk(512);
+    if (cs == 0) cs = conv_channel_split(M);
     if (span <= 3 * 128) {
-        if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<true, 3>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
-        else hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 3>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+        if (R) launch_v5_cw<true, 3>(cs, g, blk, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+        else launch_v5_cw<false, 3>(cs, g, blk, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
         return true;
     }
     if (span <= 4 * 128) {
-        if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<true, 4>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
-        else hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 4>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+        if (R) launch_v5_cw<true, 4>(cs, g, blk, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+        else launch_v5_cw<false, 4>(cs, g, blk, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
         return true;
     }
     return false;

@@ -18,7 +18,13 @@
 
 // up to this many board points per forward the small-batch convolution is used (16 boards of 19x19)
 #ifndef SMALL_BATCH_POINTS
-#define SMALL_BATCH_POINTS 5776
+#define SMALL_BATCH_POINTS 4332   // 12 boards of 19x19: above it the channel-split slab kernel is faster
+#endif
+#ifndef GRAPH_MAX_POINTS
+#define GRAPH_MAX_POINTS 46208    // forwards up to 128 boards of 19x19 are replayed as captured graphs
+#endif
+#ifndef DEVICE_COUNT_MIN_POINTS
+#define DEVICE_COUNT_MIN_POINTS 23104  // batches from here on may take their size from device memory
 #endif
 
 struct Tower {
@@ -369,7 +375,7 @@ void launch_conv<bf16_t>(const Tower *t, const bf16_t *X, const bf16_t *Wt, cons
     dim3 grid((M + 127) / 128, t->C / 128), block(256);
     // a few positions only: spread them over many small workgroups instead of a handful of 256-point tiles
     if (M <= SMALL_BATCH_POINTS && cin % 32 == 0 && t->C % 64 == 0) {
-        if (M <= SMALL_BATCH_POINTS / 8) launch_small<8, 2, 9>(X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C, st);
+        if (M <= 722) launch_small<8, 2, 9>  /* one or two 19x19 boards */(X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C, st);
         else launch_small<4, 4, 3>(X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C, st);
         return;
     }
@@ -440,7 +446,7 @@ static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float
 bool tower_takes_device_count(const Tower *t, int B)
 {
     return t->dtype == 1 && t->C == 256 && CIN0 == 32 && conv_slab_span(t->HW, t->W, t->PP) <= 4 * 128 && B >= 1 && B <= t->maxB &&
-           (size_t)B * t->HW > 4 * (size_t)SMALL_BATCH_POINTS;  // below that a half-empty batch belongs to the small-batch kernels
+           (size_t)B * t->HW > (size_t)DEVICE_COUNT_MIN_POINTS;  // below that a half-empty batch belongs to the kernels for few boards
 }
 
 int tower_forward(Tower *t, const int8_t *planes_dev, int B, float *priors_dev, float *values_dev, hipStream_t st, std::string &err,
@@ -450,7 +456,7 @@ int tower_forward(Tower *t, const int8_t *planes_dev, int B, float *priors_dev, 
     if (B < 1 || B > t->maxB) { err = "batch exceeds the tower's activation buffers"; return -1; }
     if (count_dev && !tower_takes_device_count(t, B)) { err = "this tower shape needs the batch size on the host"; return -1; }
     t->evs_used = 0;
-    const bool graphable = t->use_graphs && !t->profile && !count_dev && (size_t)B * t->HW <= SMALL_BATCH_POINTS;
+    const bool graphable = t->use_graphs && !t->profile && !count_dev && (size_t)B * t->HW <= GRAPH_MAX_POINTS;
     if (graphable) {
         for (auto &g : t->graphs)
             if (g.B == B && g.planes == planes_dev && g.priors == priors_dev && g.values == values_dev && g.rows == rows_dev && g.st == st) {

@@ -1,6 +1,6 @@
 // Dev harness: correctness + timing of the tower's 3x3 256->256 bf16 convolution kernels.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/conv_bench.hip -o tools/conv_bench
-//   tools/conv_bench [boards=1024] [iters=20] [variant=0] [resid=1] [check=1]
+//   tools/conv_bench [boards=1024] [iters=20] [variant=0] [resid=1] [check=1] [channel_split=0]
 #include "../alphazero_amd/csrc/az_conv_kernels.h"
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +34,7 @@ int main(int argc, char **argv)
 {
     int B = argc > 1 ? atoi(argv[1]) : 1024, iters = argc > 2 ? atoi(argv[2]) : 20, variant = argc > 3 ? atoi(argv[3]) : 0;
     int resid = argc > 4 ? atoi(argv[4]) : 1, check = argc > 5 ? atoi(argv[5]) : 1;
+    int cs = argc > 6 ? atoi(argv[6]) : 0;  // channel split of the slab kernel (1, 2, 4; 0 = automatic)
     const int H = 19, Wd = 19, HW = 361, PP = 441, C = 256;
     const int M = B * HW;
     size_t act = (size_t)B * PP * C;
@@ -63,7 +64,7 @@ int main(int argc, char **argv)
             else hipLaunchKernelGGL((k_conv3x3_c256_bf16<false>), g, blk, 0, 0, X, Wt, bias, (const bf16_t *)nullptr, Y, M, HW, Wd, PP);
             break;
         case 5:
-            if (!launch_v5(X, Wt, bias, resid ? R : nullptr, Y, M, HW, Wd, PP)) { printf("slab kernel not applicable\n"); exit(1); }
+            if (!launch_v5(X, Wt, bias, resid ? R : nullptr, Y, M, HW, Wd, PP, 0, nullptr, cs)) { printf("slab kernel not applicable\n"); exit(1); }
             break;
         }
     };
