@@ -353,60 +353,6 @@ __device__ __forceinline__ void conv_epilogue(unsigned char *smem, const int *ro
     }
 }
 
-// Epilogue without an LDS round trip.  acc[i][j][r] is channel wc*64 + i*16 + (lane>>4)*4 + r of the
-// tile's point wr*128 + j*16 + (lane&15).  v_permlane16_swap of the registers of blocks i and i+1 leaves
-// every lane with 8 consecutive channels of one block (lane rows 0/2: block i, rows 1/3: block i+1), i.e.
-// one 16-byte piece of the NHWC row: bias, residual and ReLU are applied in fp32, rounded to bf16 once,
-// and stored.  Needs only `rowoff` from LDS, so no barrier is required before it.
-template <bool RESID, bool PRE = true>
-__device__ __forceinline__ void conv_epilogue_direct(const int *rowoff, f32x4 (&acc)[4][8], const float *__restrict__ bias,
-                                                     const bf16_t *__restrict__ R, bf16_t *__restrict__ Y, int M, int m0, int lane_in,
-                                                     int wr, int wc, const uint4 (&rpre)[8])
-{
-    constexpr int C = 256;
-    int lane = lane_in;
-    asm volatile("" : "+v"(lane));  // keeps the address arithmetic below from being hoisted above the K loop
-    const int q = lane >> 4, px = lane & 15;
-#pragma unroll
-    for (int ip = 0; ip < 2; ip++) {
-        const int ch = wc * 64 + (ip * 2 + (q & 1)) * 16 + (q >> 1) * 8;
-        const float4 b0 = *reinterpret_cast<const float4 *>(bias + ch), b1 = *reinterpret_cast<const float4 *>(bias + ch + 4);
-        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        long off[8];
-        bool ok[8];
-        uint4 rres[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int trow = wr * 128 + j * 16 + px;
-            ok[j] = m0 + trow < M;
-            off[j] = (long)rowoff[trow] * C + ch;
-            if (RESID) {  // rows past M are clamped to a valid row in rowoff, so the load needs no predicate
-                if (PRE && ip == 0) rres[j] = rpre[j];  // PRE: the caller fetched the first block pair's pieces earlier
-                else rres[j] = *reinterpret_cast<const uint4 *>(R + off[j]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            float v[8];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ip * 2][j][r]), __float_as_uint(acc[ip * 2 + 1][j][r]), false, false);
-                v[r] = __uint_as_float(sw[0]);
-                v[4 + r] = __uint_as_float(sw[1]);
-            }
-            const unsigned rr[4] = {rres[j].x, rres[j].y, rres[j].z, rres[j].w};
-            unsigned out[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                float lo = v[2 * k] + bb[2 * k], hi = v[2 * k + 1] + bb[2 * k + 1];
-                if (RESID) { lo += __uint_as_float(rr[k] << 16); hi += __uint_as_float(rr[k] & 0xffff0000u); }
-                out[k] = pack_bf16(fmaxf(lo, 0.f), fmaxf(hi, 0.f));
-            }
-            if (ok[j]) *reinterpret_cast<uint4 *>(Y + off[j]) = make_uint4(out[0], out[1], out[2], out[3]);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
 // Raw workgroup barrier for the ping-pong schedule of the slab kernel below (no implicit waitcnt, so
 // LDS-DMA stays in flight across it).  With -DSTAMP (development harness only) one workgroup records
@@ -591,20 +537,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
     // One MFMA interval: 32 MFMAs with this wave's share of the LDS-DMA slipped in after the first rows.
     // dw = how many half-steps ahead the weights are fetched (3 for group 0, 2 for group 1, which issues
     // one interval later); slab_tap = the tap at which the next chunk's slab is issued.
-    // residual pieces of channel blocks 0/1 in the epilogue's layout, fetched during the last intervals of the K loop
-#if defined(EPI_DIRECT)
-    constexpr int NPF = RESID ? 8 : 0;
-#else
-    constexpr int NPF = 0;
-#endif
-    uint4 rpre[8];
-    auto prefetch_resid = [&]() {
-        const int q = lane >> 4;
-        const unsigned ch = wc * 64 + (q & 1) * 16 + (q >> 1) * 8;
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            rpre[j] = *reinterpret_cast<const uint4 *>(R + ((size_t)((unsigned)rowoff[wr * 128 + j * 16 + (lane & 15)] * C + ch)));
-    };
     auto mfma_interval = [&](int cc, int tap, int dw, int slab_tap) {
         __builtin_amdgcn_s_setprio(1);
         mfma_rows(0, 1);
@@ -612,7 +544,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
         const int tn = tap + dw;
         if (tn < 9) issue_w(cc, tn);
         else if (cc < NCC - 1) issue_w(cc + 1, tn - 9);
-        else if (NPF != 0 && tap == 6) prefetch_resid();
         __builtin_amdgcn_sched_barrier(0);
         mfma_rows(1, NI < 2 ? NI : 2);
         __builtin_amdgcn_sched_barrier(0);
@@ -627,13 +558,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
     auto retire_g0 = [&](int cc, int tap) {  // end of group 0's MFMA interval of (cc, tap); issued up to W(h+3)
         if (cc < NCC - 1) { if (tap < 3) wait_vmcnt<2 * WB + NSP>(); else wait_vmcnt<2 * WB>(); }
         else if (tap <= 5) wait_vmcnt<2 * WB>();
-        else if (tap == 6) wait_vmcnt<WB + NPF>();
-        else wait_vmcnt<NPF>();
+        else if (tap == 6) wait_vmcnt<WB>();
+        else wait_vmcnt<0>();
     };
     auto retire_g1 = [&](int cc, int tap) {  // end of group 1's read interval of (cc, tap); issued up to W(h+2)
         if (cc < NCC - 1) { if (tap == 1 || tap == 2) wait_vmcnt<WB + NSP>(); else wait_vmcnt<WB>(); }
         else if (tap <= 6) wait_vmcnt<WB>();
-        else wait_vmcnt<NPF>();  // the prefetch was issued in the MFMA interval of (7, 6), one interval earlier
+        else wait_vmcnt<0>();
     };
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #ifdef ONE_BAR
@@ -688,20 +619,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
     // states an MFMA result needs before a vector ALU read: cover the longest case by hand
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #endif
-    // measured in the self-play bench: LDS-transpose epilogue 1225 TFLOP/s, register-swap epilogue 1193, mixed 1214
-#if defined(EPI_DIRECT)
-    constexpr bool kLdsEpilogue = false;
-#else
-    constexpr bool kLdsEpilogue = true;
-#endif
-    if (kLdsEpilogue) {
-        __syncthreads();
-        conv_epilogue<RESID, NI>(smem, rowoff, acc, bias, R, Y, M, m0, wave, lane, wr, cout0 + wc * CW);
-    } else {
-#if defined(EPI_DIRECT)
-        conv_epilogue_direct<RESID>(rowoff, acc, bias, R, Y, M, m0, lane, wr, wc, rpre);
-#endif
-    }
+    // (a register-swap epilogue without the LDS round trip measured 1-3 % slower in the self-play bench)
+    __syncthreads();
+    conv_epilogue<RESID, NI>(smem, rowoff, acc, bias, R, Y, M, m0, wave, lane, wr, cout0 + wc * CW);
 }
 
 // largest number of padded positions (incl. the one-row-plus-one halo on both sides) that a tile of
