@@ -138,3 +138,25 @@ def test_float32_and_float64_searches_refuse_each_others_inputs():
         e64.step_finish()                                        # no tower outputs for a float64 search
     e32.close()
     e64.close()
+
+
+def test_graph_replay_equals_plain_launches(monkeypatch):
+    """Forwards of small batches are captured once and replayed as a HIP graph: outputs must be bit-identical to plain
+    launches, on the capturing call, on replays, and when batch sizes alternate."""
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.network.model import fold_to_blob, random_net
+    H, NB, C = 19, 2, 256
+    blob = fold_to_blob(random_net(H, H, 362, NB, C, seed=8, perturb_bn=True))
+    x = (np.random.RandomState(2).rand(40, 17, H, H) < 0.3).astype(np.int8)
+    monkeypatch.delenv("AZ_NO_GRAPHS", raising=False)
+    graphs = Engine("go", H, H, n_slots=40, num_blocks=NB, channels=C, tower_dtype="bf16")
+    monkeypatch.setenv("AZ_NO_GRAPHS", "1")          # read when the tower is created
+    plain = Engine("go", H, H, n_slots=40, num_blocks=NB, channels=C, tower_dtype="bf16")
+    for e in (graphs, plain):
+        e.tower_load(blob)
+    for B in (1, 5, 1, 32, 5, 40, 32, 1):
+        pg, vg = graphs.tower_forward(x[:B])
+        pp, vp = plain.tower_forward(x[:B])
+        assert np.array_equal(pg, pp) and np.array_equal(vg, vp), B
+    graphs.close()
+    plain.close()
