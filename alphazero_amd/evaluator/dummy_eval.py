@@ -1,4 +1,10 @@
-"""Drop-in for AlphaZero.evaluator.dummy_eval: uniform priors, value 0 (float64, as the reference)."""
+"""Evaluator without a network: every action gets the same prior and the value is 0.
+
+Takes the place of AlphaZero/evaluator/dummy_eval.py:18-28.  The priors are Python/NumPy float64 and the value is the
+int 0, exactly as there, so a search fed by it runs its N/W/P arithmetic in double precision (the drop-in MCTSearch
+notices and uses the float64 engine).
+"""
+import functools
 import os
 
 import numpy as np
@@ -6,24 +12,39 @@ import yaml
 
 from ..processing.state_converter import TensorActionConverter
 
-_cfg_dir = os.path.join(os.path.dirname(__file__), '..', 'config')
-with open(os.path.join(_cfg_dir, 'game.yaml')) as f:
-    game_selection = yaml.safe_load(f)['game']
-with open(os.path.join(_cfg_dir, game_selection + '.yaml')) as c:
-    game_config = yaml.safe_load(c)
+
+@functools.lru_cache(maxsize=None)
+def default_game_config():
+    """The game named in config/game.yaml, read the first time an evaluator is built without a config of its own."""
+    cfg_dir = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), os.pardir, "config"))
+    with open(os.path.join(cfg_dir, "game.yaml")) as fh:
+        chosen = yaml.safe_load(fh)["game"]
+    with open(os.path.join(cfg_dir, "%s.yaml" % chosen)) as fh:
+        return yaml.safe_load(fh)
 
 
 class DummyEvaluator:
     def __init__(self, config=None):
-        self._config = config or game_config
-        self._t2a = TensorActionConverter(self._config)
+        cfg = config if config is not None else default_game_config()
+        self._n_actions = int(cfg["flat_move_output"])
+        self._label = TensorActionConverter(cfg).tensor_to_action
 
+    # the reference's evaluator contract: checkpoints are no-ops here
     def load(self, save_dir):
-        pass
+        return None
 
     def save(self, save_dir):
-        pass
+        return None
 
     def eval(self, state):
-        dims = self._config['flat_move_output']
-        return self._t2a.tensor_to_action(np.full((dims,), 1 / dims)), 0
+        uniform = np.full((self._n_actions,), 1 / self._n_actions)
+        return self._label(uniform), 0
+
+
+def __getattr__(name):
+    """`game_config` and `game_selection`, module attributes in the reference's file, resolved on first use."""
+    if name == "game_config":
+        return default_game_config()
+    if name == "game_selection":
+        return default_game_config()["name"]
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
