@@ -34,6 +34,9 @@ struct az_engine {
     bool compact = true;  // run the tower only on the leaf rows that need it, when its kernels can take the count from the device
     int32_t *net_first = nullptr, *net_rows = nullptr, *net_cnt = nullptr;  // [G], [2][G], [2]
     unsigned long long *net_tot = nullptr;  // [2] boards each network has evaluated, summed on the device
+    int16_t *pop_moves = nullptr;   // staging of az_trajectory_pop_many, grown on demand
+    int32_t *pop_visits = nullptr;
+    size_t pop_rows = 0;
     // staging
     int32_t *st_a = nullptr, *st_b = nullptr, *st_c = nullptr, *st_d = nullptr, *st_e = nullptr;  // [max(G,64)] each
     uint8_t *st_bytes = nullptr;   // [G * max(O, 17*NC)]
@@ -106,6 +109,8 @@ extern "C" void az_engine_destroy(az_engine *h)
     if (h->tower2) tower_destroy(h->tower2);
     for (void *p : h->allocs) hipFree(p);
     for (void *p : h->rng_bufs) if (p) hipFree(p);
+    if (h->pop_moves) hipFree(h->pop_moves);
+    if (h->pop_visits) hipFree(h->pop_visits);
     for (int q = 0; q < AZ_EVQ; q++)
         for (int i = 0; i < 4; i++) if (h->ev[q][i]) hipEventDestroy(h->ev[q][i]);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -807,6 +812,55 @@ extern "C" int az_trajectory_pop(az_engine *h, int32_t slot, int16_t *moves, int
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return np;
+}
+
+extern "C" int az_trajectory_pop_many(az_engine *h, const int32_t *slots, int32_t n, const int32_t *row_start, int32_t total_rows,
+                                      int16_t *moves, int32_t *visits, int32_t *winners, int32_t restart)
+{
+    int rc = check_slots(h, slots, n);
+    if (rc) return rc;
+    if (n == 0) return AZ_OK;
+    if (!row_start || !moves || !visits || !winners || total_rows < 0) return set_err(h, AZ_ERR_ARG, "null argument");
+    const Dev &D = h->D;
+    if (!D.record) return set_err(h, AZ_ERR_STATE, "the engine was created without record_trajectories");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int G = D.G;
+    std::vector<int32_t> ph(G), ply(G), win(G);
+    HIPCHK(hipMemcpyAsync(ph.data(), D.phase, sizeof(int32_t) * G, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(ply.data(), D.ply, sizeof(int32_t) * G, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(win.data(), D.tr_winner, sizeof(int32_t) * G, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    long long expect = 0;
+    for (int i = 0; i < n; i++) {
+        const int s = slots[i];
+        for (int j = 0; j < i; j++)
+            if (slots[j] == s) return set_err(h, AZ_ERR_ARG, "duplicate slot");
+        if (ph[s] != PH_GAME_DONE) return set_err(h, AZ_ERR_STATE, "a game in the list is not finished");
+        if (row_start[i] != expect) return set_err(h, AZ_ERR_ARG, "row_start is not the running sum of the games' plies");
+        expect += std::min(ply[s], D.traj_plies);
+    }
+    if (expect != total_rows) return set_err(h, AZ_ERR_ARG, "total_rows does not match the games' plies");
+    if ((size_t)total_rows > h->pop_rows) {
+        if (h->pop_moves) hipFree(h->pop_moves);
+        if (h->pop_visits) hipFree(h->pop_visits);
+        h->pop_moves = nullptr; h->pop_visits = nullptr; h->pop_rows = 0;
+        const size_t rows = (size_t)total_rows + (size_t)total_rows / 2 + 64;
+        HIPCHK(hipMalloc((void **)&h->pop_moves, rows * sizeof(int16_t)));
+        HIPCHK(hipMalloc((void **)&h->pop_visits, rows * D.geo.O * sizeof(int32_t)));
+        h->pop_rows = rows;
+    }
+    if ((rc = up(h, h->st_a, slots, n)) || (rc = up(h, h->st_b, row_start, n))) return rc;
+    hipLaunchKernelGGL(k_traj_gather, dim3(n), dim3(256), 0, h->stream, h->D, (const int32_t *)h->st_a, (const int32_t *)h->st_b, n,
+                       h->pop_moves, h->pop_visits);
+    if (total_rows > 0) {
+        HIPCHK(hipMemcpyAsync(moves, h->pop_moves, sizeof(int16_t) * (size_t)total_rows, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(visits, h->pop_visits, sizeof(int32_t) * (size_t)total_rows * D.geo.O, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (restart) hipLaunchKernelGGL(k_reset, dim3(n), dim3(64), 0, h->stream, h->D, (const int32_t *)h->st_a, n, 1);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    for (int i = 0; i < n; i++) winners[i] = win[slots[i]];
+    return AZ_OK;
 }
 
 // ---- RNG replay streams ------------------------------------------------------

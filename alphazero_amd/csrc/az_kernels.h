@@ -98,6 +98,22 @@ __device__ void apply_noise(const Dev &D, int g, int t)
 // (search/mcts.py:173-217, :261-280)
 // ---------------------------------------------------------------------------
 
+// Finished games' trajectories packed back to back: block q copies the rows of slot slots[q] to row starts[q] of the
+// packed arrays (moves int16 per ply, visits int32[O] per ply).
+__global__ __launch_bounds__(256) void k_traj_gather(Dev D, const int32_t *__restrict__ slots, const int32_t *__restrict__ starts, int n,
+                                                    int16_t *__restrict__ moves, int32_t *__restrict__ visits)
+{
+    const int q = blockIdx.x;
+    if (q >= n) return;
+    const int g = slots[q], O = D.geo.O;
+    const int np = min(D.ply[g], D.traj_plies);
+    const size_t r0 = (size_t)starts[q];
+    for (int i = threadIdx.x; i < np; i += blockDim.x) moves[r0 + i] = D.tr_moves[(size_t)g * D.traj_plies + i];
+    const int32_t *src = D.tr_visits + (size_t)g * D.traj_plies * O;
+    int32_t *dst = visits + r0 * O;
+    for (size_t i = threadIdx.x; i < (size_t)np * O; i += blockDim.x) dst[i] = src[i];
+}
+
 #ifdef AZ_STAMP_SELECT
 // development build only: shader-clock stamps of one wavefront's phases in k_select (block 0, lane 0)
 __device__ unsigned long long g_sel_stamps[16];

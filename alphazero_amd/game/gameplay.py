@@ -156,11 +156,10 @@ class BatchedSelfplay:
         with ThreadPoolExecutor(max_workers=1) as pool:   # one worker: conversions stay in finishing order
             while n_popped < num_games:
                 self.eng.selfplay_run(rounds_per_poll)    # the C call releases the GIL: the worker converts meanwhile
-                _, done = self.eng.selfplay_status()
-                popped = []
-                for s in np.flatnonzero(done):
-                    tr = self.eng.trajectory_pop(int(s), restart=True)
-                    popped.append((tr["moves"], tr["visits"], tr["winner"]))
+                plies, done = self.eng.selfplay_status()
+                fin = np.flatnonzero(done)
+                popped = [(tr["moves"], tr["visits"], tr["winner"])
+                          for tr in self.eng.trajectory_pop_many(fin, plies[fin], restart=True)]
                 if popped:
                     n_popped += len(popped)
                     pending.append(pool.submit(self._convert, popped))
@@ -225,21 +224,21 @@ class BatchedMatch:
         finished = 0
         while finished < self.num_games:
             eng.selfplay_run(rounds_per_poll)
-            _, done = eng.selfplay_status()
-            for s in np.flatnonzero(done):
-                s = int(s)
-                if game_of_slot[s] is None:
-                    continue
-                more = next_game < self.num_games
-                tr = eng.trajectory_pop(s, restart=more)
-                winners[game_of_slot[s]] = tr["winner"]
-                finished += 1
-                if more:
-                    game_of_slot[s] = next_game
-                    eng.match_assign([s], [0 if colors[next_game] == 1 else 1])
-                    next_game += 1
-                else:
-                    game_of_slot[s] = None
+            plies, done = eng.selfplay_status()
+            fin = [int(s) for s in np.flatnonzero(done) if game_of_slot[int(s)] is not None]
+            n_more = min(len(fin), self.num_games - next_game)
+            again, last = fin[:n_more], fin[n_more:]      # slots that take another game / that stay empty
+            for group, restart in ((again, True), (last, False)):
+                for s, tr in zip(group, eng.trajectory_pop_many(group, plies[group], restart=restart)):
+                    winners[game_of_slot[s]] = tr["winner"]
+                    finished += 1
+            for s in again:
+                game_of_slot[s] = next_game
+                next_game += 1
+            if again:
+                eng.match_assign(again, [0 if colors[game_of_slot[s]] == 1 else 1 for s in again])
+            for s in last:
+                game_of_slot[s] = None
         win_counter, num_not_tie, accepted = gating_verdict(winners, colors)
         return {"win_counter": win_counter, "num_not_tie": num_not_tie, "win_rate": win_counter / (num_not_tie + 1e-9),
                 "accepted": accepted, "winners": winners, "colors_of_new": colors}

@@ -185,6 +185,11 @@ int az_selfplay_status(az_engine *h, int32_t *plies /* n_slots */, int32_t *done
  * Returns n_plies, or AZ_ERR_STATE if the slot's game is not finished. */
 int az_trajectory_pop(az_engine *h, int32_t slot, int16_t *moves, int32_t *visits, int32_t *winner, int32_t restart);
 int az_trajectory_max_plies(az_engine *h);
+/* The same for n finished slots in one call (one synchronisation, one packed copy): the games' rows lie back to back,
+ * game i at rows row_start[i] .. row_start[i] + plies_i of moves[total_rows] and visits[total_rows][O]; row_start must be
+ * the running sum of the plies az_selfplay_status reported and total_rows their sum (checked). winners[n]. */
+int az_trajectory_pop_many(az_engine *h, const int32_t *slots, int32_t n, const int32_t *row_start, int32_t total_rows,
+                           int16_t *moves, int32_t *visits, int32_t *winners, int32_t restart);
 
 /* ---- RNG (numpy.random.randint / random.gammavariate / random.choices) - */
 /* replay streams for one slot: transform ids, gamma draws, move-choice uniforms */

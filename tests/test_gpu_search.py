@@ -297,3 +297,36 @@ def test_queued_search_rounds_equal_the_stepwise_loop(K):
         for x, y in zip(a[:4], b[:4]):
             assert np.array_equal(x, y)
         assert a[1].sum() == P
+
+
+def test_batched_trajectory_pop_equals_single_pops():
+    from alphazero_amd.engine import Engine, EngineError
+    G, P = 12, 10
+    engs = [Engine("mnk", 3, 3, 3, n_slots=G, max_playout=P, seed=9, record_trajectories=True) for _ in range(2)]
+    rng = np.random.RandomState(0)
+    for e in engs:
+        e.selfplay_start()
+    for _ in range(9 * (P + 1) + 3):
+        pri = rng.dirichlet(np.ones(9), size=G).astype(np.float32)
+        val = rng.uniform(-1, 1, G).astype(np.float32)
+        for e in engs:
+            e.selfplay_select()
+            e.selfplay_finish(pri, val)
+    (pa, da), (pb, db) = engs[0].selfplay_status(), engs[1].selfplay_status()
+    assert np.array_equal(pa, pb) and np.all(da == 1)
+    order = [7, 0, 11, 3]
+    many = engs[0].trajectory_pop_many(order, pa[order], restart=True)
+    for s, tr in zip(order, many):
+        one = engs[1].trajectory_pop(s, restart=True)
+        assert np.array_equal(tr["moves"], one["moves"]) and np.array_equal(tr["visits"], one["visits"]) and tr["winner"] == one["winner"]
+        assert len(tr["moves"]) == pa[s]
+    for e in engs:                                   # the popped slots were re-armed, the others still wait
+        plies, done = e.selfplay_status()
+        assert all(done[s] == 0 and plies[s] == 0 for s in order) and done.sum() == G - len(order)
+    assert engs[0].trajectory_pop_many([], []) == []
+    with pytest.raises(EngineError):
+        engs[0].trajectory_pop_many([7], [0])        # re-armed: not finished
+    with pytest.raises(EngineError):
+        engs[0].trajectory_pop_many([1, 2], [pa[1] + 1, pa[2]])   # ply counts that do not match the device
+    for e in engs:
+        e.close()
