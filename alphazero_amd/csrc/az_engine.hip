@@ -420,9 +420,12 @@ extern "C" int az_search_begin(az_engine *h, const int32_t *slots, int32_t n, co
 static int launch_select(az_engine *h)
 {
     HIPCHK(hipMemsetAsync(h->D.ctr + (size_t)AZ_CTR_BUCKETS * C_N, 0, sizeof(unsigned long long) * AZ_CTR_BUCKETS, h->stream));
-    for (int sub = 0; sub < h->D.K; sub++) {
-        if (h->D.f64) hipLaunchKernelGGL(k_select<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
-        else hipLaunchKernelGGL(k_select<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
+    if (h->D.K > 1) {  // all sub-rounds of a leaves_per_round > 1 search inside one launch
+        if (h->D.f64) hipLaunchKernelGGL(k_select_all<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
+        else hipLaunchKernelGGL(k_select_all<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
+    } else {
+        if (h->D.f64) hipLaunchKernelGGL(k_select<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, 0);
+        else hipLaunchKernelGGL(k_select<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, 0);
     }
     HIPCHK(hipGetLastError());
     return AZ_OK;
@@ -547,10 +550,8 @@ static int step_finish(az_engine *h, const void *priors, const void *values, int
     HIPCHK(hipSetDevice(h->cfg.device));
     int rc = evaluate(h, priors, values, f64);
     if (rc) return rc;
-    for (int sub = 0; sub < h->D.K; sub++) {
-        if (h->D.f64) hipLaunchKernelGGL(k_finish<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
-        else hipLaunchKernelGGL(k_finish<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
-    }
+    if (h->D.f64) hipLaunchKernelGGL(k_finish<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, -1);
+    else hipLaunchKernelGGL(k_finish<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, -1);
     HIPCHK(hipGetLastError());
     h->steps++;
     return check_slot_errors(h);
@@ -665,10 +666,8 @@ extern "C" int az_selfplay_start(az_engine *h)
 
 static void launch_tail(az_engine *h)
 {
-    for (int sub = 0; sub < h->D.K; sub++) {
-        if (h->D.f64) hipLaunchKernelGGL(k_finish<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
-        else hipLaunchKernelGGL(k_finish<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
-    }
+    if (h->D.f64) hipLaunchKernelGGL(k_finish<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, -1);
+    else hipLaunchKernelGGL(k_finish<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, -1);
     hipLaunchKernelGGL(k_move, dim3(h->D.G), dim3(64), 0, h->stream, h->D);
     if (h->D.f64) hipLaunchKernelGGL(k_reroot<double>, dim3(2 * h->D.G), dim3(64), 0, h->stream, h->D);
     else hipLaunchKernelGGL(k_reroot<float>, dim3(2 * h->D.G), dim3(64), 0, h->stream, h->D);
@@ -731,10 +730,8 @@ extern "C" int az_search_run(az_engine *h, int32_t n_rounds)
         int rc = launch_select(h);
         if (rc) return rc;
         if ((rc = evaluate(h, nullptr, nullptr))) return rc;
-        for (int sub = 0; sub < h->D.K; sub++) {
-            if (h->D.f64) hipLaunchKernelGGL(k_finish<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
-            else hipLaunchKernelGGL(k_finish<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, sub);
-        }
+        if (h->D.f64) hipLaunchKernelGGL(k_finish<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, -1);
+        else hipLaunchKernelGGL(k_finish<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, -1);
         h->steps++;
     }
     HIPCHK(hipGetLastError());

@@ -123,9 +123,8 @@ __device__ unsigned long long g_sel_stamps[16];
 #endif
 
 template <typename R>
-__global__ __launch_bounds__(64) void k_select(Dev D, int sub)
+__device__ __forceinline__ void select_one(const Dev &D, const int sub, WLds &L)
 {
-    __shared__ WLds L;
     R *const eW = static_cast<R *>(D.eW);
     const R *const eP = static_cast<const R *>(D.eP);
     const int g = blockIdx.x;
@@ -276,12 +275,34 @@ __global__ __launch_bounds__(64) void k_select(Dev D, int sub)
     }
 }
 
+// k_select: one sub-round.  k_select_all: all leaves_per_round sub-rounds one after the other in one launch; they are
+// sequential by construction (each sees the virtual losses of the ones before), and one wavefront per game runs them
+// in program order, so fusing them only saves the launches.
+template <typename R>
+__global__ __launch_bounds__(64) void k_select(Dev D, int sub)
+{
+    __shared__ WLds L;
+    select_one<R>(D, sub, L);
+}
+
+// (a kernel of its own: inside the loop the compiler keeps so much lane-invariant state in registers that the single
+// sub-round form, which serves thousands of games at once, would drop to one wave per SIMD)
+template <typename R>
+__global__ __launch_bounds__(64) void k_select_all(Dev D)
+{
+    __shared__ WLds L;
+    for (int j = 0; j < D.K; j++) {
+        select_one<R>(D, j, L);
+        WSYNC();
+    }
+}
+
 // ---------------------------------------------------------------------------
 // finish: expand or terminal value, then backup (mcts.py:217-232, 196-202, 283)
 // ---------------------------------------------------------------------------
 
 template <typename R>
-__global__ __launch_bounds__(64) void k_finish(Dev D, int sub)
+__device__ __forceinline__ void finish_one(const Dev &D, const int sub)
 {
     R *const eW = static_cast<R *>(D.eW);
     R *const eP = static_cast<R *>(D.eP);
@@ -384,6 +405,17 @@ __global__ __launch_bounds__(64) void k_finish(Dev D, int sub)
         int pd = D.pdone[g] + 1;
         D.pdone[g] = pd;
         if (pd >= D.max_playout) D.phase[g] = PH_SEARCH_DONE;
+    }
+}
+
+// sub as in k_select: one sub-round, or (sub < 0) all of them in order within one launch
+template <typename R>
+__global__ __launch_bounds__(64) void k_finish(Dev D, int sub)
+{
+    const int first = sub >= 0 ? sub : 0, last = sub >= 0 ? sub + 1 : D.K;
+    for (int j = first; j < last; j++) {
+        finish_one<R>(D, j);
+        WSYNC();
     }
 }
 
