@@ -85,8 +85,9 @@ def test_batched_match_counts_like_the_reference():
     assert (out["win_counter"], out["num_not_tie"], out["accepted"]) == gating_verdict(out["winners"], out["colors_of_new"])
 
 
-@pytest.mark.parametrize("game,H,k,G,P,rounds", [("reversi", 8, 0, 400, 6, 70 * 7), ("mnk", 8, 4, 400, 5, 66 * 6)])
-def test_leaf_compaction_changes_nothing_but_the_work(game, H, k, G, P, rounds):
+@pytest.mark.parametrize("game,H,k,G,P,rounds,K", [("reversi", 8, 0, 400, 6, 70 * 7, 1), ("mnk", 8, 4, 400, 5, 66 * 6, 1),
+                                                    ("reversi", 8, 0, 400, 6, 70 * 5, 2)])   # two leaf rows per slot
+def test_leaf_compaction_changes_nothing_but_the_work(game, H, k, G, P, rounds, K):
     """Whole games with many finished-game leaves near the end: the tower run on the compacted rows only (device-side
     row list and count) gives the same trajectories, bit for bit, as the tower run on every row, and evaluates fewer
     boards."""
@@ -97,7 +98,7 @@ def test_leaf_compaction_changes_nothing_but_the_work(game, H, k, G, P, rounds):
     out = []
     for compact in (True, False):
         eng = Engine(game, H, H, k, n_slots=G, max_playout=P, transform_types=8, dirichlet_before=4, max_turn=400,
-                     record_trajectories=True, seed=5, num_blocks=1, channels=256, tower_dtype="bf16")
+                     record_trajectories=True, seed=5, num_blocks=1, channels=256, tower_dtype="bf16", leaves_per_round=K)
         eng.tower_load(blob)
         eng.tower_leaf_compaction(compact)
         eng.selfplay_start()
@@ -111,5 +112,5 @@ def test_leaf_compaction_changes_nothing_but_the_work(game, H, k, G, P, rounds):
     assert np.array_equal(pa, pb) and na == nb
     for a, b in zip(ta, tb):
         assert np.array_equal(a["moves"], b["moves"]) and np.array_equal(a["visits"], b["visits"]) and a["winner"] == b["winner"]
-    assert eb == rounds * G            # every row of every round
+    assert eb == rounds * G * K        # every row of every round
     assert ea < na <= eb               # only live, non-terminal leaves: fewer than the playouts counted
