@@ -339,9 +339,13 @@ extern "C" int az_rules_do_move(az_engine *h, const int32_t *slots, int32_t n, c
     if (rc) return rc;
     if (n == 0) return AZ_OK;
     if (!actions || !status) return set_err(h, AZ_ERR_ARG, "null argument");
-    for (int i = 0; i < n; i++)
-        for (int j = 0; j < i; j++)
-            if (slots[i] == slots[j]) return set_err(h, AZ_ERR_ARG, "duplicate slot in one do_move batch");
+    {
+        std::vector<char> seen(h->D.G, 0);
+        for (int i = 0; i < n; i++) {
+            if (seen[slots[i]]) return set_err(h, AZ_ERR_ARG, "duplicate slot in one do_move batch");
+            seen[slots[i]] = 1;
+        }
+    }
     HIPCHK(hipSetDevice(h->cfg.device));
     if ((rc = up(h, h->st_a, slots, n)) || (rc = up(h, h->st_b, actions, n))) return rc;
     if (colors && (rc = up(h, h->st_c, colors, n))) return rc;
@@ -828,10 +832,11 @@ extern "C" int az_trajectory_pop_many(az_engine *h, const int32_t *slots, int32_
     HIPCHK(hipMemcpyAsync(win.data(), D.tr_winner, sizeof(int32_t) * G, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     long long expect = 0;
+    std::vector<char> seen(G, 0);
     for (int i = 0; i < n; i++) {
         const int s = slots[i];
-        for (int j = 0; j < i; j++)
-            if (slots[j] == s) return set_err(h, AZ_ERR_ARG, "duplicate slot");
+        if (seen[s]) return set_err(h, AZ_ERR_ARG, "duplicate slot");
+        seen[s] = 1;
         if (ph[s] != PH_GAME_DONE) return set_err(h, AZ_ERR_STATE, "a game in the list is not finished");
         if (row_start[i] != expect) return set_err(h, AZ_ERR_ARG, "row_start is not the running sum of the games' plies");
         expect += std::min(ply[s], D.traj_plies);
