@@ -416,7 +416,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
                                                                 bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP, int npos,
                                                                 const int32_t *__restrict__ cnt)
 {
-    constexpr int C = 256, NCC = CIN / 32, SLAB_BYTES = NSP * 128 * 64;  // C output channels, NCC 32-channel input chunks
+    constexpr int NCC = CIN / 32, SLAB_BYTES = NSP * 128 * 64;  // NCC 32-channel input chunks; 256 output channels in all
     constexpr int NI = CW / 16;            // 16-channel MFMA blocks per wave
     constexpr int WROWS = 4 * CW;          // weight rows (output channels) of this workgroup
     constexpr int WB = CW == 64 ? 2 : 1;   // LDS-DMA loads per wave and weight batch (16 rows each)
