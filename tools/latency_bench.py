@@ -29,7 +29,7 @@ for B in (1, 2, 4, 8, 16, 17, 32, 64):
     print("tower forward B=%3d: %7.3f ms  (%8.1f evals/s)" % (B, dt * 1e3, B / dt), flush=True)
 eng.close()
 
-for K in (1, 4, 8, 16, 32):
+for K in (1, 4, 8, 16, 32, 64):
     e = Engine("go", H, H, n_slots=1, max_playout=800, transform_types=8, num_blocks=NB, channels=256, tower_dtype="bf16", seed=3,
                leaves_per_round=K)
     e.tower_load(blob)
