@@ -9,7 +9,8 @@
 #include <string>
 #include <vector>
 
-static std::string g_create_error;
+// why the last az_engine_create of the calling thread failed (there is no handle to hang the message on)
+static thread_local std::string g_create_error;
 #define AZ_EVQ 8
 
 #define HIPCHK(call)                                                                          \

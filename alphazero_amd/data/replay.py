@@ -44,25 +44,21 @@ class ReplayPool:
                 self.count += 1
 
     def merge_data(self, data):
-        """Ring overwrite exactly as datapool.py:87-112 (a batch that crosses the end wraps to the front)."""
+        """Appends the rows of one game at the ring's write position, wrapping over the oldest rows; the position and
+        the `is_full` / `training_started` flags follow datapool.py:87-112 (a batch ending exactly at the capacity
+        leaves the position at the capacity and only the next batch marks the ring full)."""
+        n, cap, end = len(data[0]), self.pool_capacity, self.pool_end_index
+        if n > cap:
+            raise ValueError("a game of %d rows does not fit a pool of %d" % (n, cap))
         if self.data_pool is None:
-            self.data_pool = []
-            for item in data:
-                shape = [*item.shape]
-                shape[0] = self.pool_capacity
-                self.data_pool.append(np.zeros(shape))
-        n, cap, end = data[0].shape[0], self.pool_capacity, self.pool_end_index
-        if not end + n > cap:
-            for i, item in enumerate(data):
-                self.data_pool[i][end:end + n] = item
-            self.pool_end_index = end + n
-        else:
-            self.is_full = True
-            for i, item in enumerate(data):
-                self.data_pool[i][end:cap] = item[:cap - end]
-                self.data_pool[i][:n - cap + end] = item[cap - end:]
-            self.pool_end_index = n - cap + end
-        if (not self.training_started) and (self.is_full or self.pool_end_index > self.start_data_size):
+            self.data_pool = [np.zeros((cap,) + np.shape(item)[1:]) for item in data]
+        where = (end + np.arange(n)) % cap
+        for ring, item in zip(self.data_pool, data):
+            ring[where] = item
+        wrapped = end + n > cap
+        self.is_full = self.is_full or wrapped
+        self.pool_end_index = end + n - cap if wrapped else end + n
+        if self.is_full or self.pool_end_index > self.start_data_size:
             self.training_started = True
 
     def put(self, data):

@@ -28,8 +28,7 @@ def history_arrays(eng, moves, visits, winner, slot=0):
         status, _ = eng.do_move([slot], [int(moves[i])])
         assert status[0] == 0
     probs_np = np.asarray(visits, np.float64) / np.asarray(visits, np.float64).sum(axis=1, keepdims=True) if T else np.zeros((0, O))
-    result_np = np.array([1.0 if (i % 2 == (winner != 1)) else -1.0 for i in range(T)])
-    return state_np, probs_np, result_np
+    return state_np, probs_np, outcome_labels(T, winner)
 
 
 def history_arrays_batch(eng, games):
@@ -53,60 +52,70 @@ def history_arrays_batch(eng, games):
         T = lens[k]
         v = np.asarray(visits, np.float64)
         probs_np = v / v.sum(axis=1, keepdims=True) if T else np.zeros((0, O))
-        result_np = np.array([1.0 if (i % 2 == (winner != 1)) else -1.0 for i in range(T)])
-        out.append((states[k], probs_np, result_np))
+        out.append((states[k], probs_np, outcome_labels(T, winner)))
     return out
 
 
+def outcome_labels(n_plies, winner, black=1):
+    """result_np of game/gameplay.py:93: ply i is labelled +1 when the side to move at ply i (Black on even plies)
+    is the winner; a draw (winner 0) is labelled as a White win, as the reference does."""
+    black_to_move = (np.arange(n_plies) % 2) == 0
+    return np.where(black_to_move == (winner == black), 1.0, -1.0)
+
+
 class Game:
+    """One game between two evaluators (game/gameplay.py:17-94): Game(nn_eval_1, nn_eval_2, game_config, ext_config),
+    start() -> winner, get_history() -> (state_np, probs_np, result_np); player_1 moves first."""
+
     def __init__(self, nn_eval_1, nn_eval_2, game_config, ext_config):
-        self.player_1 = player.Player(nn_eval_1, game_config, ext_config['player'])
-        self.player_2 = player.Player(nn_eval_2, game_config, ext_config['player'])
-        self._game_env = importlib.import_module(game_config['env_path'])
-        self.state = self._game_env.GameState()
+        env = importlib.import_module(game_config['env_path'])
+        self._pass, self._black = env.PASS_MOVE, env.BLACK
+        self.state = env.GameState()
+        self.player_1, self.player_2 = (player.Player(ev, game_config, ext_config['player']) for ev in (nn_eval_1, nn_eval_2))
         self.winner = None
-        self.state_history = []
-        self.probs_history = []
-        self.acts_history = []
-        self._w = game_config['board_width']
-        self._h = game_config['board_height']
-        self._f = game_config['history_step'] * game_config['planes_per_step'] + game_config['additional_planes']
-        self._o = game_config['flat_move_output']
-        self.dirichlet_before = ext_config['dirichlet_before']
-        self.log_iter = ext_config['log_iter']
-        self.max_turn = ext_config['max_turn']
+        self._shape = (game_config['history_step'] * game_config['planes_per_step'] + game_config['additional_planes'],
+                       game_config['board_height'], game_config['board_width'])
+        self._n_actions = game_config['flat_move_output']
+        self.dirichlet_before, self.log_iter, self.max_turn = (ext_config[k] for k in ('dirichlet_before', 'log_iter', 'max_turn'))
+        self._plies = []   # per ply: (planes of the pre-move state, [(action, pi)], move)
+
+    # the reference keeps three parallel lists; they are views of the ply records here
+    state_history = property(lambda self: [p[0] for p in self._plies])
+    probs_history = property(lambda self: [p[1] for p in self._plies])
+    acts_history = property(lambda self: [p[2] for p in self._plies])
+
+    def _ply(self):
+        st = self.state
+        mover = self.player_2 if len(self._plies) & 1 else self.player_1
+        move, probs = mover.think(st, st.turns <= self.dirichlet_before)
+        self._plies.append((st.features(0), probs, move))
+        st.do_move(move)
+        for p in (self.player_1, self.player_2):   # both trees follow every move
+            p.ack(move)
 
     def start(self):
-        current_player = self.player_1
-        while not (self.state.is_end_of_game or self.state.turns > self.max_turn):
-            if self.state.turns % self.log_iter == 0:
-                printlog(str(self.state.turns), 'moves')
-            move, probs = current_player.think(self.state, (self.state.turns <= self.dirichlet_before))
-            self.state_history.append(self.state.features(0))  # planes of the pre-move state
-            self.probs_history.append(probs)
-            self.acts_history.append(move)
-            self.state.do_move(move)
-            self.player_1.ack(move)
-            self.player_2.ack(move)
-            current_player = self.player_2 if current_player == self.player_1 else self.player_1
-        self.winner = self.state.get_winner()
+        st = self.state
+        while not st.is_end_of_game and st.turns <= self.max_turn:
+            if st.turns % self.log_iter == 0:
+                printlog(str(st.turns), 'moves')
+            self._ply()
+        self.winner = st.get_winner()
         printlog('end', self.winner)
         return self.winner
 
+    def _flat(self, action):
+        _, h, w = self._shape
+        return h * w if action == self._pass else action[0] * w + action[1]
+
     def get_history(self):
-        n = len(self.probs_history)
-        state_np = np.zeros((len(self.state_history), self._f, self._h, self._w))
-        probs_np = np.zeros((n, self._o))
-        result_np = np.zeros((n))
-        for i in range(n):
-            state_np[i] = self.state_history[i]
-            for action, p in self.probs_history[i]:
-                if action == self._game_env.PASS_MOVE:
-                    probs_np[i, self._w * self._h] = p
-                else:
-                    probs_np[i, action[0] * self._w + action[1]] = p
-            result_np[i] = 1 if (i % 2 == (self.winner != self._game_env.BLACK)) else -1
-        return state_np, probs_np, result_np
+        T = len(self._plies)
+        state_np = np.zeros((T,) + self._shape)
+        probs_np = np.zeros((T, self._n_actions))
+        for i, (planes, probs, _) in enumerate(self._plies):
+            state_np[i] = planes
+            if probs:
+                probs_np[i, [self._flat(a) for a, _ in probs]] = [p for _, p in probs]
+        return state_np, probs_np, outcome_labels(T, self.winner, self._black)
 
 
 class BatchedSelfplay:
