@@ -50,6 +50,8 @@ class AzCounters(C.Structure):
         ("tower_calls", C.c_uint64), ("tower_evals", C.c_uint64),
         ("conv_ms", C.c_double), ("conv_launches", C.c_uint64), ("conv_flops_per_launch", C.c_double),
         ("expansions_skipped", C.c_uint64),
+        ("peak_tree_edges", C.c_uint64), ("peak_tree_blocks", C.c_uint64),
+        ("tree_edge_cap", C.c_uint64), ("tree_block_cap", C.c_uint64),
     ]
 
 
@@ -73,6 +75,7 @@ SIGNATURES = {
     "az_search_begin": (_I, [_P, _P, _I, _P, _P]),
     "az_search_step_select": (_I, [_P, _P]),
     "az_leaf_batch": (_I, [_P, _P, _P]),
+    "az_leaf_outputs": (_I, [_P, _P, _P]),
     "az_search_step_finish": (_I, [_P, _P, _P]),
     "az_search_root_stats": (_I, [_P, _I, _I, _P, _P, _P, _P, _P]),
     "az_search_choose": (_I, [_P, _I, _I, C.c_double, _P]),

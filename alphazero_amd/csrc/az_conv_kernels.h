@@ -825,7 +825,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_f32(const float *__restrict__ X
     const int lrow = tid >> 2, lk = (tid & 3) * 4;
     const size_t abase = (size_t)rowoff[lrow] * CIN + lk;
     const size_t wbase = (size_t)(n0 + lrow) * 9 * CIN + lk;
-    float acc[4][4] = {};
+    // double accumulators: a product of two floats is exact in double and the 9 * CIN-term sum then carries no visible
+    // rounding, so each layer's output is the correctly rounded float of its exact value (the 1e-5 parity mode has to
+    // hold through 41 layers; float accumulation left 1e-5 on the value of a 20-block tower)
+    double acc[4][4] = {};
     for (int tap = 0; tap < 9; tap++) {
         const long toff = (long)((tap / 3 - 1) * W2 + (tap % 3 - 1)) * CIN;
         for (int c0 = 0; c0 < CIN; c0 += 16) {
@@ -843,7 +846,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_f32(const float *__restrict__ X
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+                    for (int j = 0; j < 4; j++) acc[i][j] = fma((double)av[i], (double)bv[j], acc[i][j]);
             }
         }
     }
@@ -855,8 +858,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_f32(const float *__restrict__ X
         for (int j = 0; j < 4; j++) {
             const int n = n0 + tx * 4 + j;
             size_t o = (size_t)rowoff[row] * COUT + n;
-            float v = acc[i][j] + bias[n];
-            if (RESID) v += R[o];
+            float v = (float)(acc[i][j] + (double)bias[n] + (RESID ? (double)R[o] : 0.0));
             Y[o] = fmaxf(v, 0.0f);
         }
     }

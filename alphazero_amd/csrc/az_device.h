@@ -97,6 +97,9 @@ struct Dev {
     // counters: AZ_CTR_BUCKETS rows of C_N (a workgroup adds into row blockIdx.x % AZ_CTR_BUCKETS, so thousands of
     // workgroups do not queue on one address), then AZ_CTR_BUCKETS words for the round's leaf count; the host sums
     unsigned long long *ctr;
+    // largest number of edges / expanded nodes any tree has held since the counters were reset: AZ_CTR_BUCKETS pairs,
+    // a workgroup raises the pair of its bucket (the host takes the maximum)
+    int32_t *peak;
 };
 
 #define WSYNC() __syncthreads()

@@ -49,7 +49,10 @@ struct az_engine {
     // AZ_EVQ ahead of the host, their phase times folded in when their quad is reused or the call ends
     hipEvent_t ev[AZ_EVQ][4];
     int ev_head = 0, ev_pending = 0;
-    bool conv_profile = false;
+    bool conv_profile = false;      // per-launch conv timing on every round (host waits for each round)
+    int prof_every = 0;             // > 0: per-launch conv timing on every prof_every-th round only, rounds stay queued
+    bool ev_prof[AZ_EVQ] = {};      // the queued round of this event quad carries the tower's per-launch events
+    uint64_t round_index = 0;
     double tower_ms = 0, select_ms = 0, finish_ms = 0;
     uint64_t tower_calls = 0, tower_evals = 0, steps = 0;
     bool started = false;
@@ -131,6 +134,8 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
         return nullptr;
     }
     if (cfg->game == AZ_REVERSI && (H != W || (H & 1))) { g_create_error = "reversi needs an even square board"; return nullptr; }
+    if (!(cfg->d_epsilon >= 0.0 && cfg->d_epsilon <= 1.0)) { g_create_error = "d_epsilon must lie in [0, 1]"; return nullptr; }
+    if (!cfg->rng_replay && !(cfg->d_alpha > 0.0)) { g_create_error = "d_alpha must be positive (random.gammavariate raises otherwise)"; return nullptr; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_error = "no HIP device"; return nullptr; }
     if (hipSetDevice(cfg->device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return nullptr; }
@@ -201,6 +206,7 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     A(tr_visits, int32_t, (size_t)G * D.traj_plies * O);
     A(tr_winner, int32_t, G);
     A(ctr, unsigned long long, (size_t)AZ_CTR_BUCKETS * (C_N + 1));
+    A(peak, int32_t, (size_t)AZ_CTR_BUCKETS * 2);
 #undef A
 #undef AR
     const size_t stn = std::max(G, 64);
@@ -465,6 +471,18 @@ extern "C" int az_leaf_batch(az_engine *h, int8_t *planes, uint8_t *valid)
     return AZ_OK;
 }
 
+extern "C" int az_leaf_outputs(az_engine *h, float *priors, float *values)
+{
+    if (!h) return AZ_ERR_ARG;
+    if (h->D.f64) return set_err(h, AZ_ERR_ARG, "engine searches in float64: its evaluator outputs are the caller's own arrays");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const size_t LG = (size_t)h->D.K * h->D.G;
+    if (priors) HIPCHK(hipMemcpyAsync(priors, h->D.priors, sizeof(float) * LG * h->D.geo.O, hipMemcpyDeviceToHost, h->stream));
+    if (values) HIPCHK(hipMemcpyAsync(values, h->D.values, sizeof(float) * LG, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return AZ_OK;
+}
+
 // Two-network rounds without a read-back: both towers take the device-side batch size, and the slot count is large
 // enough that the slab kernels (the only ones that read it) are the right choice even for a half-empty batch.
 static bool two_nets_async(const az_engine *h)
@@ -474,7 +492,7 @@ static bool two_nets_async(const az_engine *h)
 }
 
 // priors / values: host arrays of the engine's statistic type (f64 says which the caller passed), or NULL = run the tower
-static int evaluate(az_engine *h, const void *priors, const void *values, int f64 = 0)
+static int evaluate(az_engine *h, const void *priors, const void *values, int f64 = 0, bool full_batch = false)
 {
     const int G = h->D.G, O = h->D.geo.O, LG = h->D.K * h->D.G;
     if ((priors == nullptr) != (values == nullptr)) return set_err(h, AZ_ERR_ARG, "priors and values must both be given or both NULL");
@@ -520,7 +538,7 @@ static int evaluate(az_engine *h, const void *priors, const void *values, int f6
         }
         return AZ_OK;
     }
-    if (h->compact && !h->conv_profile && tower_takes_device_count(h->tower, LG)) {
+    if (h->compact && !h->conv_profile && !full_batch && tower_takes_device_count(h->tower, LG)) {
         // terminal leaves and idle slots stay out of the batch: the surviving rows are listed on the device and the
         // tower's kernels read their number there (per-launch conv timing measures full batches, so it turns this off)
         hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, h->D, LG, h->net_rows, h->net_cnt, h->net_tot);
@@ -688,7 +706,8 @@ static int drain_round(az_engine *h)
     hipEventElapsedTime(&b, ev[1], ev[2]);
     hipEventElapsedTime(&c, ev[2], ev[3]);
     h->select_ms += a; h->tower_ms += b; h->finish_ms += c;
-    if (h->conv_profile) tower_collect_profile(h->tower);
+    if (h->conv_profile || h->ev_prof[h->ev_head]) tower_collect_profile(h->tower);
+    h->ev_prof[h->ev_head] = false;
     h->steps++;
     h->ev_head = (h->ev_head + 1) % AZ_EVQ;
     h->ev_pending--;
@@ -706,12 +725,20 @@ extern "C" int az_selfplay_run(az_engine *h, int32_t n_rounds)
     const int depth = (h->conv_profile || (h->two_nets && !two_nets_async(h))) ? 1 : AZ_EVQ;
     for (int r = 0; r < n_rounds; r++) {
         if (h->ev_pending >= depth) { int rc = drain_round(h); if (rc) return rc; }
-        hipEvent_t *ev = h->ev[(h->ev_head + h->ev_pending) % AZ_EVQ];
+        const int q = (h->ev_head + h->ev_pending) % AZ_EVQ;
+        hipEvent_t *ev = h->ev[q];
+        // sampled per-launch timing: this round runs the full batch with events around its conv launches; the rounds
+        // are at least AZ_EVQ apart, so the one set of events is never in flight twice (one network only)
+        const bool sample = h->prof_every > 0 && !h->two_nets && (h->round_index % (uint64_t)h->prof_every) == 0;
+        h->round_index++;
         HIPCHK(hipEventRecord(ev[0], h->stream));
         int rc = launch_select(h);
         if (rc) return rc;
         HIPCHK(hipEventRecord(ev[1], h->stream));
-        if ((rc = evaluate(h, nullptr, nullptr))) return rc;
+        if (sample) tower_set_profile(h->tower, true);
+        rc = evaluate(h, nullptr, nullptr, 0, sample);
+        if (sample) { tower_set_profile(h->tower, false); h->ev_prof[q] = true; }
+        if (rc) return rc;
         HIPCHK(hipEventRecord(ev[2], h->stream));
         launch_tail(h);
         HIPCHK(hipEventRecord(ev[3], h->stream));
@@ -1006,8 +1033,10 @@ extern "C" int az_tower_profile(az_engine *h, int32_t on)
     if (!h || !h->tower) return AZ_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    tower_set_profile(h->tower, on != 0);
-    h->conv_profile = on != 0;
+    if (on < 0 || (on > 1 && on < AZ_EVQ)) return set_err(h, AZ_ERR_ARG, "az_tower_profile: 0, 1, or a sampling period of at least 8 rounds");
+    tower_set_profile(h->tower, on == 1);
+    h->conv_profile = on == 1;
+    h->prof_every = on > 1 ? on : 0;
     return AZ_OK;
 }
 
@@ -1047,6 +1076,14 @@ extern "C" int az_counters_get(az_engine *h, az_counters *out)
         HIPCHK(hipMemcpy(tot, h->net_tot, sizeof tot, hipMemcpyDeviceToHost));
         out->tower_evals += tot[0] + tot[1];
     }
+    {
+        int32_t pk[AZ_CTR_BUCKETS * 2];
+        HIPCHK(hipMemcpy(pk, h->D.peak, sizeof pk, hipMemcpyDeviceToHost));
+        int32_t pe = 0, pb = 0;
+        for (int b = 0; b < AZ_CTR_BUCKETS; b++) { pe = std::max(pe, pk[2 * b]); pb = std::max(pb, pk[2 * b + 1]); }
+        out->peak_tree_edges = pe; out->peak_tree_blocks = pb;
+        out->tree_edge_cap = h->D.EC; out->tree_block_cap = h->D.BC;
+    }
     out->conv_ms = 0; out->conv_launches = 0; out->conv_flops_per_launch = 0;
     if (h->tower) {
         unsigned long long n = 0;
@@ -1066,6 +1103,7 @@ extern "C" int az_counters_reset(az_engine *h)
     h->tower_ms = h->select_ms = h->finish_ms = 0;
     h->tower_calls = h->tower_evals = h->steps = 0;
     HIPCHK(hipMemset(h->net_tot, 0, 2 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(h->D.peak, 0, sizeof(int32_t) * AZ_CTR_BUCKETS * 2));
     if (h->tower) { double a; unsigned long long b; tower_profile_read(h->tower, &a, &b, true); }
     return AZ_OK;
 }

@@ -45,14 +45,31 @@ __device__ double rng_uniform(const Dev &D, int g)
     return rng_u01(D, g);
 }
 
-// gamma(alpha, 1) for alpha <= 1 (Ahrens-Dieter GS, the algorithm CPython's
-// random.gammavariate uses); per-lane independent draw from a hashed stream
-__device__ double gamma_small(double alpha, unsigned long long key)
+// gamma(alpha, 1), the three algorithms of CPython's random.gammavariate (math_helper.py:13-17 calls it with
+// alpha = d_alpha, beta = 1): Ahrens-Dieter GS for alpha < 1, the exponential for alpha == 1, Cheng's rejection
+// method for alpha > 1.  Per-lane independent draw from a hashed stream; the rejection loops are bounded (a draw is
+// accepted with probability > 0.5 per trial in every branch).
+__device__ double gamma_variate(double alpha, unsigned long long key)
 {
+    auto u01 = [&](int i) { return (double)(mix64(key + (unsigned long long)i) >> 11) * (1.0 / 9007199254740992.0); };
     double x = 0.0;
+    if (alpha > 1.0) {
+        const double ainv = sqrt(2.0 * alpha - 1.0), bbb = alpha - 1.3862943611198906, ccc = alpha + ainv;
+        for (int it = 0; it < 64; it++) {
+            const double u1 = u01(2 * it);
+            if (!(1e-7 < u1 && u1 < 0.9999999)) continue;
+            const double u2 = 1.0 - u01(2 * it + 1);
+            const double v = log(u1 / (1.0 - u1)) / ainv;
+            x = alpha * exp(v);
+            const double z = u1 * u1 * u2, r = bbb + ccc * v - x;
+            if (r + 2.504077396776274 - 4.5 * z >= 0.0 || r >= log(z)) break;
+        }
+        return x;
+    }
+    if (alpha == 1.0) return -log(1.0 - u01(0));
     for (int it = 0; it < 64; it++) {
-        double u = (double)(mix64(key + 2 * it) >> 11) * (1.0 / 9007199254740992.0);
-        double u1 = (double)(mix64(key + 2 * it + 1) >> 11) * (1.0 / 9007199254740992.0);
+        double u = u01(2 * it);
+        double u1 = u01(2 * it + 1);
         double bb = (2.718281828459045 + alpha) / 2.718281828459045;
         double p = bb * u;
         x = p <= 1.0 ? pow(p, 1.0 / alpha) : -log((bb - p) / alpha);
@@ -85,7 +102,7 @@ __device__ void apply_noise(const Dev &D, int g, int t)
         key = rng_u64(D, g);
     }
     for (int c = lane; c < n; c += AZ_WAVE) {
-        double eta = D.rng_replay ? D.re[g][base + c] : gamma_small(D.d_alpha, key + 1000ULL * (unsigned long long)(c + 1));
+        double eta = D.rng_replay ? D.re[g][base + c] : gamma_variate(D.d_alpha, key + 1000ULL * (unsigned long long)(c + 1));
         R p = eP[tb + start + c];
         R a = keep * p;
         eP[tb + start + c] = a + (R)(D.d_epsilon * eta);
@@ -371,6 +388,9 @@ __device__ __forceinline__ void finish_one(const Dev &D, const int sub)
                 D.bStart[bb + bi] = start; D.bCount[bb + bi] = n;
                 D.bOwner[bb + bi] = node; D.bParent[bb + bi] = D.leaf_block[li];
                 D.nBlocks[t] = bi + 1; D.nEdges[t] = start + n;
+                int32_t *pk = D.peak + 2 * (blockIdx.x & (AZ_CTR_BUCKETS - 1));
+                if (start + n > pk[0]) atomicMax(&pk[0], start + n);
+                if (bi + 1 > pk[1]) atomicMax(&pk[1], bi + 1);
                 if (node == NODE_ROOT) D.rootBlock[t] = bi; else D.eChild[tb + node] = bi;
                 atomicAdd(&D.ctr[(size_t)(blockIdx.x & (AZ_CTR_BUCKETS - 1)) * C_N + C_EDGES], (unsigned long long)n);
             }

@@ -455,7 +455,7 @@ int tower_forward(Tower *t, const int8_t *planes_dev, int B, float *priors_dev, 
     if (!t->ready) { err = "weights not loaded"; return -1; }
     if (B < 1 || B > t->maxB) { err = "batch exceeds the tower's activation buffers"; return -1; }
     if (count_dev && !tower_takes_device_count(t, B)) { err = "this tower shape needs the batch size on the host"; return -1; }
-    t->evs_used = 0;
+    if (t->profile) t->evs_used = 0;  // (a sampled forward's events wait for tower_collect_profile across later forwards)
     const bool graphable = t->use_graphs && !t->profile && !count_dev && (size_t)B * t->HW <= GRAPH_MAX_POINTS;
     if (graphable) {
         for (auto &g : t->graphs)

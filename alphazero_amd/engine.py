@@ -148,6 +148,13 @@ class Engine:
         self._ck(self._L.az_leaf_batch(self._h, planes.ctypes.data, valid.ctypes.data))
         return planes, valid
 
+    def leaf_outputs(self):
+        """(priors (K*G, O), values (K*G,)) float32 as the last finish step used them; rows that took no evaluation
+        are stale."""
+        p = np.zeros((self.K * self.G, self.O), np.float32); v = np.zeros(self.K * self.G, np.float32)
+        self._ck(self._L.az_leaf_outputs(self._h, p.ctypes.data, v.ctypes.data))
+        return p, v
+
     def step_finish(self, priors=None, values=None):
         if priors is None:
             self._ck(self._L.az_search_step_finish(self._h, None, None))
@@ -287,6 +294,7 @@ class Engine:
         return p, v
 
     def tower_profile(self, on=True):
+        """False/0: off; True/1: per-launch conv timing on every round; N >= 8: on every N-th round only."""
         self._ck(self._L.az_tower_profile(self._h, int(on)))
 
     def tower_leaf_compaction(self, on=True):

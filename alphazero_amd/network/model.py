@@ -139,3 +139,21 @@ def random_net(board_height, board_width, flat_move_output, num_blocks, channels
                 m.beta.data.copy_(torch.randn(m.beta.shape, generator=g) * 0.1)
     torch.random.set_rng_state(state)
     return net.eval()
+
+
+def calibrate_bn(net, x):
+    """Sets every batch norm's moving mean / variance to the statistics of its input on the batch x (float (B,17,H,W)),
+    layer by layer, as the moving averages of a network that has trained on such data would be.  A randomly initialised
+    tower with untouched statistics (mean 0, variance 1) roughly doubles its activation variance per residual block
+    (there is no BN scale), which after 20 blocks leaves logits of magnitude 50 and more; calibrated, every layer's
+    output is unit-scale."""
+    bns = [m for m in net.modules() if isinstance(m, CenterBN)]
+    old = [m.decay for m in bns]
+    for m in bns:
+        m.decay = 0.0          # running statistics <- this batch's statistics
+    net.train()
+    with torch.no_grad():
+        net(x)
+    for m, d in zip(bns, old):
+        m.decay = d
+    return net.eval()

@@ -5,12 +5,15 @@ over the GPUs of one node with the weights broadcast over RCCL.
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one round of the hot path over every game slot of a GPU: PUCT select (rule replay down to
+A "round" is one pass of the hot path over every game slot of a GPU: PUCT select (rule replay down to
 one leaf per game) -> feature planes -> tower forward over the leaf batch -> expand/backup ->
-(when a search is complete) move choice, real move, re-root of both trees.  One step therefore
-consumes one network evaluation (= one MCTS simulation) per game.  Inputs are synthetic: seeded
-glorot-uniform weights, games start from the empty board, device RNG seed 0; everything is resident
-in HBM before the timed region.  Rank 0 prints one JSON line.
+(when a search is complete) move choice, real move, re-root of both trees; it consumes one network
+evaluation (= one MCTS simulation) per game.  A "step" is a fixed block of rounds, one twentieth of a
+move's search rounded up (41 rounds at 800 sims/move), so that the default 20 timed steps carry every
+game through the end of a search, the move and the re-root of both trees: `value` is the number of
+moves completed inside the timed region per second.  Inputs are synthetic: seeded glorot-uniform
+weights, games start from the empty board, device RNG seed 0; everything is resident in HBM before
+the timed region.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -105,17 +108,20 @@ def hbm_kernels(c, cells, O, steps, peak_gbs=8000.0):
     for name, nbytes, ms in (("k_select", sel_bytes, c["select_ms"]), ("k_finish+k_move+k_reroot", fin_bytes, c["finish_ms"])):
         gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         out.append({"kernel": name, "bound": "hbm", "achieved": gbs, "peak": peak_gbs, "unit": "GB/s", "frac": gbs / peak_gbs,
-                    "bytes_per_sim": nbytes / ev, "ms_per_step": ms / steps})
+                    "bytes_per_sim": nbytes / ev, "ms_per_round": ms / steps})
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # default: a little more than one full 801-evaluation search per game, so that every game also goes through
-    # move choice, the real move and the re-root of both trees inside the timed region (about 12 s on one MI355X)
-    ap.add_argument("--steps", type=int, default=810)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rounds-per-step", type=int, default=0,
+                    help="rounds (one simulation per game each) in a step; 0 = ceil((sims + 1) / 20), i.e. 20 steps are a "
+                         "little more than one whole search per game (about 45 s on one MI355X at the default workload)")
+    ap.add_argument("--profile-every", type=int, default=16,
+                    help="per-launch HIP-event timing of the tower's conv launches on every N-th round of the timed region")
     ap.add_argument("--games", type=int, default=0,
                     help="concurrent games per GPU; 0 = 4096, or fewer if the GPU's free memory does not hold their trees")
     ap.add_argument("--game", default="go", choices=["go", "reversi", "mnk"],
@@ -178,7 +184,11 @@ def main():
     blob = parallel.broadcast_weights(blob, eng.tower_blob_floats(), dist, torch.device("cuda", local_rank))
     eng.tower_load(blob)
     eng.selfplay_start()
-    eng.tower_profile(True)
+    rps = args.rounds_per_step if args.rounds_per_step > 0 else -(-(args.sims + 1) // 20)
+    rounds, warm_rounds = args.steps * rps, args.warmup * rps
+    # the headline rate is measured in the production mode (leaf compaction on, rounds queued ahead of the host); every
+    # profile_every-th round additionally carries HIP events around each of its conv launches for the roofline figure
+    eng.tower_profile(max(8, args.profile_every))
 
     def barrier():
         if dist is not None:
@@ -186,11 +196,11 @@ def main():
         torch.cuda.synchronize()
         eng.sync()
 
-    eng.selfplay_run(args.warmup)
+    eng.selfplay_run(warm_rounds)
     eng.counters_reset()
     barrier()
     t0 = time.perf_counter()
-    eng.selfplay_run(args.steps)
+    eng.selfplay_run(rounds)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -198,13 +208,18 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     c = eng.counters()
-    evals = torch.tensor([float(c["evals"]), float(c["moves"])], dtype=torch.float64, device="cuda")
+    evals = torch.tensor([float(c["evals"]), float(c["moves"]), float(c["expansions_skipped"]), float(args.games)],
+                         dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(evals, op=dist.ReduceOp.SUM)
-    total_evals, total_moves = float(evals[0].item()), float(evals[1].item())
+    total_evals, total_moves, total_skipped, total_games = (float(x) for x in evals.tolist())
     sims_per_s = total_evals / dt
     evals_per_move = args.sims + 1  # a search costs max_playout evaluations, +1 when its root is still a leaf
-    moves_per_s = sims_per_s / evals_per_move
+    steady_moves_per_s = sims_per_s / evals_per_move
+    # moves that really completed (search end, move choice, real move, both re-roots) inside the timed region; a region
+    # shorter than one search completes none and only the evaluation-count figure exists
+    whole_searches = total_moves >= total_games
+    moves_per_s = total_moves / dt if whole_searches else steady_moves_per_s
 
     if rank == 0:
         conv_ms = c["conv_ms"] / max(c["conv_launches"], 1)
@@ -213,7 +228,11 @@ def main():
         out = {
             "metric": "self-play moves/sec + MCTS sims/sec (node), Go 19x19 800 sims, 1/2/4/8 GPUs",
             "value": moves_per_s, "unit": "moves/s", "sims_per_sec": sims_per_s,
+            "value_kind": "moves completed in the timed region / time" if whole_searches else
+                          "sims/s / (sims + 1): the timed region is shorter than one search",
+            "steady_state_moves_per_sec": steady_moves_per_s,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
+            "rounds_per_step": rps, "ms_per_round": dt * 1e3 / rounds,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {
                 "workload": "%s %dx%d self-play, %d sims/move, stem + %d residual blocks x %d ch dual-head ResNet, "
@@ -225,17 +244,26 @@ def main():
                 "tower_gflop_per_eval": eng.tower_flops_per_eval() / 1e9,
             },
             "moves_completed_in_timed_region": total_moves, "completed_moves_per_sec": total_moves / dt,
-            "phase_ms_per_step": {"select": c["select_ms"] / args.steps, "tower": c["tower_ms"] / args.steps,
-                                  "finish_move_reroot": c["finish_ms"] / args.steps},
+            "phase_ms_per_round": {"select": c["select_ms"] / rounds, "tower": c["tower_ms"] / rounds,
+                                   "finish_move_reroot": c["finish_ms"] / rounds},
+            # tree_full_policy 0 here: an arena overflow would have stopped the run with an error, so 0 skipped
+            # expansions is by construction; the peak shows how far the fullest tree of rank 0 got
+            "expansions_skipped": total_skipped,
+            "tree_arena_peak": {"edges": c["peak_tree_edges"], "edge_cap": c["tree_edge_cap"],
+                                "blocks": c["peak_tree_blocks"], "block_cap": c["tree_block_cap"],
+                                "frac": max(c["peak_tree_edges"] / max(c["tree_edge_cap"], 1),
+                                            c["peak_tree_blocks"] / max(c["tree_block_cap"], 1))},
             "tree_stats_per_sim": {"levels": c["levels"] / max(c["evals"], 1), "children_scanned": c["children_scanned"] / max(c["evals"], 1)},
             "roofline": {
                 "bound": "mfma", "kernel": "k_conv3x3_c256_bf16_slab (3x3 256->256 implicit GEMM, bf16 MFMA 16x16x32)",
                 "achieved": achieved, "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_PEAK_TFLOPS_BF16, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": conv_ms, "launches": c["conv_launches"], "flops_per_launch": c["conv_flops_per_launch"],
+                "timing": "HIP events on the launch stream around every conv launch of every %d-th round of the timed "
+                          "region (full batch in those rounds)" % max(8, args.profile_every),
             },
             # HBM-side kernels: algorithmic bytes from the engine's counters / kernel time (HIP events around each phase)
-            "hbm_kernels": hbm_kernels(c, H * H, O, args.steps),
+            "hbm_kernels": hbm_kernels(c, H * H, O, rounds),
             "tower_tflops_end_to_end": (c["tower_evals"] * eng.tower_flops_per_eval()) / (c["tower_ms"] * 1e-3) / 1e12 if c["tower_ms"] > 0 else 0.0,
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only; at N>1 the other ranks would idle behind it

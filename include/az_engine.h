@@ -108,6 +108,10 @@ typedef struct az_counters {
     uint64_t conv_launches;
     double conv_flops_per_launch; /* 2 * n_slots * H*W * 9 * C^2 */
     uint64_t expansions_skipped;  /* tree_full_policy 1: expansions dropped because an arena was full */
+    uint64_t peak_tree_edges;     /* most edges / expanded nodes any one tree has held since the last reset ... */
+    uint64_t peak_tree_blocks;
+    uint64_t tree_edge_cap;       /* ... against the arena sizes in force (az_config.tree_edge_cap / tree_block_cap) */
+    uint64_t tree_block_cap;
 } az_counters;
 
 /* ---- lifetime ------------------------------------------------------- */
@@ -151,6 +155,12 @@ int az_search_step_select(az_engine *h, int32_t *n_leaves);
 /* The evaluator's view of this round's leaves (NNEvaluator.eval input,
  * evaluator/nn_eval_parallel.py:85): planes int8 (n_slots,17,H,W), valid[n_slots] */
 int az_leaf_batch(az_engine *h, int8_t *planes, uint8_t *valid);
+/* The evaluator's answers as the last finish step used them (what NNEvaluator.eval returned for each leaf,
+ * evaluator/nn_eval_parallel.py:88-92): priors (leaves_per_round*n_slots, O) and values (leaves_per_round*n_slots)
+ * float32 host arrays in the evaluator's (transformed) index order.  Rows of leaves that took no evaluation (idle
+ * slots; with leaf compaction on, finished games below the root) keep whatever an earlier round left there.
+ * Either pointer may be NULL.  Float32 engines only. */
+int az_leaf_outputs(az_engine *h, float *priors, float *values);
 /* expand / terminal handling / backup (mcts.py:217-232,196-202,283-291).
  * priors (n_slots,O) and values (n_slots) float32 host arrays, in the evaluator's
  * (transformed) index order; both NULL = run the tower on the leaf batch. */
@@ -221,8 +231,11 @@ int az_tower_forward(az_engine *h, const int8_t *planes, int32_t B, float *out_p
  * engine's stream has finished, so the outputs can be read from any stream */
 int az_tower_forward_dev(az_engine *h, const int8_t *planes_dev, int32_t B, float *out_p_dev, float *out_v_dev);
 double az_tower_flops_per_eval(az_engine *h);
-/* on=1: bracket every residual-tower convolution launch of az_selfplay_run with HIP events on the
- * launch stream and accumulate conv_ms / conv_launches in az_counters (measurement only) */
+/* Per-launch timing of the residual tower's convolutions inside az_selfplay_run: HIP events on the launch stream
+ * around every such launch, accumulated in az_counters.conv_ms / conv_launches (measurement only).
+ * on=0: off.  on=1: every round (the host then waits for each round, and every round runs the full batch).
+ * on=N>=8: every N-th round only; that round runs the full batch (no leaf compaction, so the work per launch is
+ * the nominal one), all other rounds run as in production and stay queued ahead of the host. */
 int az_tower_profile(az_engine *h, int32_t on);
 /* on=1 (the default): a round's tower pass covers only the leaf rows that need it. The reference calls its evaluator for
  * every playout and throws the answer away at a finished game (search/mcts.py:204-211 against :229-231); results are

@@ -17,7 +17,7 @@ def test_hbm_kernels_bytes_and_rates():
     assert abs(sel["bytes_per_sim"] - sel_bytes / 1000) < 1e-9
     assert abs(sel["achieved"] - sel_bytes / 2.0e-3 / 1e9) < 1e-6 and abs(sel["frac"] - sel["achieved"] / 8000.0) < 1e-12
     fin_bytes = 1000 * 5 * 362 + 18 * 300000 + 8 * 2500
-    assert abs(fin["achieved"] - fin_bytes / 1.0e-3 / 1e9) < 1e-6 and abs(fin["ms_per_step"] - 0.1) < 1e-12
+    assert abs(fin["achieved"] - fin_bytes / 1.0e-3 / 1e9) < 1e-6 and abs(fin["ms_per_round"] - 0.1) < 1e-12
 
 
 def test_measured_traffic_scales_with_boards():

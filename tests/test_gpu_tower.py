@@ -48,6 +48,152 @@ def test_tower_matches_fp32_reference(dtype, game, H, W, NB, C, B):
     eng.close()
 
 
+def _boards(B, H, W, seed=0):
+    return (np.random.RandomState(seed).rand(B, 17, H, W) < 0.3).astype(np.int8)
+
+
+def _assert_close(p, v, net, NB, x, tol):
+    rp, rv = tower_ref.forward(net.state_dict(), torch.from_numpy(x).float(), NB)
+    assert np.all(np.isfinite(p)) and np.all(np.isfinite(v))
+    assert np.abs(p - rp.numpy()).max() <= tol, np.abs(p - rp.numpy()).max()
+    assert np.abs(v - rv.numpy()).max() <= tol, np.abs(v - rv.numpy()).max()
+
+
+# Batches of more than 128 conv tiles (32768 board points) run every tile as one workgroup over all 256 output
+# channels - the instantiation self-play and the benchmark use - together with the one-chunk stem form of the same
+# kernel; 64 boards of 19x19 run the two-way channel split.  The network is evaluated on the whole batch, the fp32
+# restatement on boards from its start, middle and (partly filled) last tile.
+@pytest.mark.parametrize("game,H,B", [
+    ("go", 19, 96),        # 136 tiles, slab of 3 x 128 positions
+    ("go", 9, 410),        # 130 tiles, slab of 4 x 128 positions
+    ("reversi", 8, 520),   # 130 tiles, 4 x 128
+    ("mnk", 15, 150),      # 132 tiles
+    ("go", 19, 64),        # 91 tiles: two workgroups per tile (32 channels per wave)
+])
+def test_full_tile_conv_kernels_match_fp32_reference(game, H, B):
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.network.model import fold_to_blob, random_net
+    O = H * H + (0 if game == "mnk" else 1)
+    NB = 1
+    net = random_net(H, H, O, NB, 256, seed=H + B, perturb_bn=True)
+    eng = Engine(game, H, H, 5, n_slots=B, num_blocks=NB, channels=256, tower_dtype="bf16")
+    eng.tower_load(fold_to_blob(net))
+    x = _boards(B, H, H, seed=B)
+    p, v = eng.tower_forward(x)
+    pick = np.array([0, 1, 2, B // 2, B // 2 + 1, B - 3, B - 2, B - 1])
+    _assert_close(p[pick], v[pick], net, NB, x[pick], TOL["bf16"])
+    assert np.allclose(p.sum(axis=1), 1.0, atol=1e-4)
+    eng.close()
+
+
+def test_device_count_and_row_list_path_matches_fp32_reference():
+    """A search round whose tower pass takes its rows and their number from device memory (leaf compaction): 300 of
+    512 slots search, the tower runs on the 300 listed rows in place, and what it wrote for those leaves is compared
+    with the fp32 restatement evaluated on the planes the engine reported for them."""
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.network.model import fold_to_blob, random_net
+    H, G, NB = 9, 512, 1
+    rng = np.random.RandomState(5)
+    net = random_net(H, H, H * H + 1, NB, 256, seed=11, perturb_bn=True)
+    eng = Engine("go", H, H, n_slots=G, max_playout=4, transform_types=8, num_blocks=NB, channels=256, tower_dtype="bf16",
+                 seed=3)
+    eng.tower_load(fold_to_blob(net))
+    slots = np.sort(rng.choice(G, 300, replace=False)).astype(np.int32)
+    for _ in range(8):   # a few random legal stones so that the planes differ from slot to slot
+        mask = eng.legal_mask(slots)[:, :H * H]
+        moves = [int(rng.choice(np.flatnonzero(m))) for m in mask]
+        status, _ = eng.do_move(slots, moves)
+        assert np.all(status == 0)
+    eng.search_begin(slots, np.zeros(300, np.int32), np.zeros(300, np.int32))
+    assert eng.step_select() == 300
+    planes, valid = eng.leaf_batch()
+    assert np.array_equal(np.flatnonzero(valid), slots)
+    eng.step_finish()                      # tower on the listed rows, then expand / backup
+    p, v = eng.leaf_outputs()
+    pick = slots[[0, 1, 2, 150, 151, 297, 298, 299]]
+    _assert_close(p[pick], v[pick], net, NB, planes[pick], TOL["bf16"])
+    assert np.allclose(p[slots].sum(axis=1), 1.0, atol=1e-4)
+    # the tree got exactly these priors: root children of a searched slot, in the evaluator's index order
+    # (transform id of the leaf applied), carry p of the legal actions
+    a, n, w, pr, rn = eng.root_stats(int(slots[0]), 0)
+    assert len(a) > 0 and np.isin(pr, p[slots[0]]).all()
+    eng.close()
+
+
+def _deep_net(H, O, NB, seed):
+    """Random weights with the batch-norm statistics of every layer set from a batch of positions (then an offset
+    beta), as a trained network's moving averages are.  With untouched statistics a random 20-block tower has
+    activations that grow by about 1.5x in variance per block and policy logits of magnitude 50: its softmax then
+    amplifies bf16 rounding (a 0.59 prior moved by 0.02 in such a net), which says nothing about the kernels."""
+    from alphazero_amd.network.model import CenterBN, calibrate_bn, random_net
+    net = random_net(H, H, O, NB, 256, seed=seed)
+    calibrate_bn(net, torch.from_numpy(_boards(6, H, H, seed=seed + 100)).float())
+    g = torch.Generator().manual_seed(seed)
+    for m in net.modules():
+        if isinstance(m, CenterBN):
+            m.beta.data.copy_(torch.randn(m.beta.shape, generator=g) * 0.1)
+    return net
+
+
+# The depths the configurations name: 6 blocks (Reversi), 10 (Go 9x9, 15x15), 20 (Go 19x19), 256 channels.
+# Anchor: the restatement evaluated in float64 (the exact value of the reference's formula).
+#   fp32 tower: priors and value within 1e-5.
+#   bf16 tower: priors within 1e-2 at every depth (measured: 2e-3 and less).  The value of a *random* network of 6 and
+#   more blocks is more sensitive than 1e-2 to bf16 rounding itself: a CPU model of the same arithmetic (bf16 weights and
+#   activations, float32 accumulation: oracle/tower_ref.forward_bf16_model) lands 0.5e-2 .. 4e-2 from the float64 value,
+#   and so does the HIP tower.  (Random ReLU towers amplify perturbations from block to block, the residual stream is
+#   re-rounded after every block, and the value is one scalar read off the whole board; the priors, a softmax over
+#   small logits, move by a tenth of that.)  The bound on the value is therefore 1e-2 plus three times the CPU model's
+#   own distance from the anchor on the same boards - the kernels may not add to what the number format costs - and
+#   never more than 1e-1.
+def _depth_check(p, v, net, NB, x, dtype, H, O):
+    rp, rv = tower_ref.forward(net.state_dict(), torch.from_numpy(x).float(), NB, dtype=torch.float64)
+    rp, rv = rp.numpy(), rv.numpy()
+    assert np.all(np.isfinite(p)) and np.all(np.isfinite(v))
+    ep, ev = np.abs(p - rp).max(), np.abs(v - rv).max()
+    if dtype == "fp32":
+        assert ep <= 1e-5 and ev <= 1e-5, (ep, ev)
+        return
+    assert ep <= 1e-2, ep
+    from alphazero_amd.network.model import fold_to_blob
+    mp, mv = tower_ref.forward_bf16_model(fold_to_blob(net), torch.from_numpy(x).float(), H, H, O, NB, 256)
+    assert np.abs(mp.numpy() - p).max() <= 1e-2     # the two bf16 evaluations agree on the priors as well
+    bound = min(1e-2 + 3.0 * np.abs(mv.numpy() - rv).max(), 1e-1)
+    print("value error %.2e (bound %.2e), priors error %.2e" % (ev, bound, ep))
+    assert ev <= bound, (ev, bound)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("game,H,NB,B", [("reversi", 8, 6, 3), ("go", 9, 10, 3), ("mnk", 15, 10, 2), ("go", 19, 20, 2)])
+def test_tower_at_named_depths(dtype, game, H, NB, B):
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.network.model import fold_to_blob
+    O = H * H + (0 if game == "mnk" else 1)
+    net = _deep_net(H, O, NB, seed=NB)
+    eng = Engine(game, H, H, 5, n_slots=4, num_blocks=NB, channels=256, tower_dtype=dtype)
+    eng.tower_load(fold_to_blob(net))
+    x = _boards(B, H, H, seed=NB)
+    p, v = eng.tower_forward(x)
+    _depth_check(p, v, net, NB, x, dtype, H, O)
+    eng.close()
+
+
+@pytest.mark.parametrize("game,H,NB,B", [("reversi", 8, 6, 520), ("go", 9, 10, 410), ("go", 19, 20, 96)])
+def test_full_tile_kernels_at_named_depths(game, H, NB, B):
+    """The same depths through the full-tile bf16 kernels (the batch sizes of self-play); three boards are checked."""
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.network.model import fold_to_blob
+    O = H * H + 1
+    net = _deep_net(H, O, NB, seed=NB + 1)
+    eng = Engine(game, H, H, n_slots=B, num_blocks=NB, channels=256, tower_dtype="bf16")
+    eng.tower_load(fold_to_blob(net))
+    x = _boards(B, H, H, seed=NB + 1)
+    p, v = eng.tower_forward(x)
+    pick = np.array([0, B // 2, B - 1])
+    _depth_check(p[pick], v[pick], net, NB, x[pick], "bf16", H, O)
+    eng.close()
+
+
 def test_tower_requires_weights():
     from alphazero_amd.engine import Engine, EngineError
     eng = Engine("mnk", 3, 3, 3, n_slots=2, num_blocks=1, channels=128)
