@@ -6,12 +6,26 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 // why the last az_engine_create of the calling thread failed (there is no handle to hang the message on)
 static thread_local std::string g_create_error;
 #define AZ_EVQ 8
+
+// Staging of az_trajectory_pop_many_static: a fixed array in every GPU's memory instead of a buffer grown with
+// hipMalloc.  The name is only a host-side handle on the symbol; the address a kernel or a copy needs is asked for once
+// per device (az_engine_create, with that device current) and kept in g_scratch_ptr.
+static __device__ __align__(256) unsigned char scratch[AZ_STATIC_POP_BYTES];
+#define AZ_MAX_DEVICES 64
+static unsigned char *g_scratch_ptr[AZ_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+// layout: slots int32[256] | row starts int32[256] | phase, ply, winner int32[256] each | packed moves | packed visits
+#define SP_SLOTS 0
+#define SP_STARTS 1024
+#define SP_META 2048
+#define SP_MOVES 8192
 
 #define HIPCHK(call)                                                                          \
     do {                                                                                      \
@@ -139,7 +153,20 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_error = "no HIP device"; return nullptr; }
     if (hipSetDevice(cfg->device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return nullptr; }
+    if (cfg->device >= 0 && cfg->device < AZ_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lk(g_scratch_mutex);
+        if (!g_scratch_ptr[cfg->device]) {
+            void *p = nullptr;
+            const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !p) {
+                g_create_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+                return nullptr;
+            }
+            g_scratch_ptr[cfg->device] = static_cast<unsigned char *>(p);
+        }
+    }
     az_engine *h = new az_engine();
+    h->error.reserve(256);  // messages are set without allocating from then on
     for (int q = 0; q < AZ_EVQ; q++)
         for (int i = 0; i < 4; i++) h->ev[q][i] = nullptr;
     h->cfg = *cfg;
@@ -890,6 +917,67 @@ extern "C" int az_trajectory_pop_many(az_engine *h, const int32_t *slots, int32_
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     for (int i = 0; i < n; i++) winners[i] = win[slots[i]];
+    return AZ_OK;
+}
+
+// phase, ply and winner of the listed slots -> meta[0..n), meta[256..), meta[512..)
+__global__ void k_traj_meta(Dev D, const int32_t *__restrict__ slots, int n, int32_t *__restrict__ meta)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int g = slots[i];
+    meta[i] = D.phase[g];
+    meta[AZ_STATIC_POP_SLOTS + i] = D.ply[g];
+    meta[2 * AZ_STATIC_POP_SLOTS + i] = D.tr_winner[g];
+}
+
+extern "C" int az_trajectory_pop_many_static(az_engine *h, const int32_t *slots, int32_t n, const int32_t *row_start, int32_t total_rows,
+                                             int16_t *moves, int32_t *visits, int32_t *winners, int32_t restart)
+{
+    int rc = check_slots(h, slots, n);
+    if (rc) return rc;
+    if (n == 0) return AZ_OK;
+    if (!row_start || !moves || !visits || !winners || total_rows < 0) return set_err(h, AZ_ERR_ARG, "null argument");
+    const Dev &D = h->D;
+    if (!D.record) return set_err(h, AZ_ERR_STATE, "the engine was created without record_trajectories");
+    if (n > AZ_STATIC_POP_SLOTS) return set_err(h, AZ_ERR_ARG, "az_trajectory_pop_many_static: more than AZ_STATIC_POP_SLOTS (256) slots in one call");
+    const size_t O = D.geo.O;
+    if ((size_t)total_rows * (2 + 4 * O) > (size_t)AZ_STATIC_POP_BYTES - 16384)
+        return set_err(h, AZ_ERR_ARG, "az_trajectory_pop_many_static: the rows exceed the fixed staging array (total_rows * (2 + 4 * O) > AZ_STATIC_POP_BYTES - 16384)");
+    if (h->cfg.device < 0 || h->cfg.device >= AZ_MAX_DEVICES || !g_scratch_ptr[h->cfg.device])
+        return set_err(h, AZ_ERR_STATE, "no staging array on this device");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    unsigned char *const sp = g_scratch_ptr[h->cfg.device];   // this GPU's copy of `scratch`
+    int32_t *const d_slots = reinterpret_cast<int32_t *>(sp + SP_SLOTS);
+    int32_t *const d_starts = reinterpret_cast<int32_t *>(sp + SP_STARTS);
+    int32_t *const d_meta = reinterpret_cast<int32_t *>(sp + SP_META);
+    int16_t *const d_moves = reinterpret_cast<int16_t *>(sp + SP_MOVES);
+    int32_t *const d_visits = reinterpret_cast<int32_t *>(sp + SP_MOVES + (((size_t)total_rows * 2 + 255) & ~(size_t)255));
+    HIPCHK(hipMemcpyAsync(d_slots, slots, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_starts, row_start, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_traj_meta, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->D, (const int32_t *)d_slots, n, d_meta);
+    int32_t meta[3 * AZ_STATIC_POP_SLOTS];
+    HIPCHK(hipMemcpyAsync(meta, d_meta, sizeof meta, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    long long expect = 0;
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < i; j++)
+            if (slots[j] == slots[i]) return set_err(h, AZ_ERR_ARG, "duplicate slot");
+        if (meta[i] != PH_GAME_DONE) return set_err(h, AZ_ERR_STATE, "a game in the list is not finished");
+        if (row_start[i] != expect) return set_err(h, AZ_ERR_ARG, "row_start is not the running sum of the games' plies");
+        expect += std::min(meta[AZ_STATIC_POP_SLOTS + i], D.traj_plies);
+    }
+    if (expect != total_rows) return set_err(h, AZ_ERR_ARG, "total_rows does not match the games' plies");
+    hipLaunchKernelGGL(k_traj_gather, dim3(n), dim3(256), 0, h->stream, h->D, (const int32_t *)d_slots, (const int32_t *)d_starts, n,
+                       d_moves, d_visits);
+    if (total_rows > 0) {
+        HIPCHK(hipMemcpyAsync(moves, d_moves, sizeof(int16_t) * (size_t)total_rows, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(visits, d_visits, sizeof(int32_t) * (size_t)total_rows * O, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (restart) hipLaunchKernelGGL(k_reset, dim3(n), dim3(64), 0, h->stream, h->D, (const int32_t *)d_slots, n, 1);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    for (int i = 0; i < n; i++) winners[i] = meta[2 * AZ_STATIC_POP_SLOTS + i];
     return AZ_OK;
 }
 

@@ -227,9 +227,10 @@ class Engine:
         n = self._ck(self._L.az_trajectory_pop(self._h, slot, moves.ctypes.data, visits.ctypes.data, C.byref(w), int(restart)))
         return dict(moves=moves[:n].copy(), visits=visits[:n].copy(), winner=w.value)
 
-    def trajectory_pop_many(self, slots, plies, restart=False):
+    def trajectory_pop_many(self, slots, plies, restart=False, static=False):
         """Trajectories of several finished slots with one device round trip; `plies` are the slots' ply counts from
-        selfplay_status().  Returns a list of dicts like trajectory_pop."""
+        selfplay_status().  Returns a list of dicts like trajectory_pop.  static=True goes through
+        az_trajectory_pop_many_static (fixed staging array inside the library, no allocation on the device)."""
         s = _i32(slots)
         if s.size == 0:
             return []
@@ -240,8 +241,9 @@ class Engine:
         total = int(n_rows.sum())
         moves = np.empty(max(total, 1), np.int16); visits = np.empty((max(total, 1), self.O), np.int32)
         win = np.zeros(s.size, np.int32)
-        self._ck(self._L.az_trajectory_pop_many(self._h, s.ctypes.data, s.size, start.ctypes.data, total, moves.ctypes.data,
-                                                visits.ctypes.data, win.ctypes.data, int(restart)))
+        fn = self._L.az_trajectory_pop_many_static if static else self._L.az_trajectory_pop_many
+        self._ck(fn(self._h, s.ctypes.data, s.size, start.ctypes.data, total, moves.ctypes.data, visits.ctypes.data,
+                    win.ctypes.data, int(restart)))
         return [dict(moves=moves[a:a + k].copy(), visits=visits[a:a + k].copy(), winner=int(w))
                 for a, k, w in zip(start.tolist(), n_rows.tolist(), win.tolist())]
 

@@ -200,6 +200,16 @@ int az_trajectory_max_plies(az_engine *h);
  * the running sum of the plies az_selfplay_status reported and total_rows their sum (checked). winners[n]. */
 int az_trajectory_pop_many(az_engine *h, const int32_t *slots, int32_t n, const int32_t *row_start, int32_t total_rows,
                            int16_t *moves, int32_t *visits, int32_t *winners, int32_t restart);
+/* az_trajectory_pop_many for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc); it has no counterpart in the reference.  Same arguments and results, but the device-side
+ * staging of the packed rows is a fixed array inside the library (one per GPU, AZ_STATIC_POP_BYTES, held until the
+ * process ends) instead of a buffer grown on demand, and the call makes no device or host allocation.  Limits:
+ * n <= AZ_STATIC_POP_SLOTS and total_rows * (2 + 4 * O) <= AZ_STATIC_POP_BYTES - 16384, else AZ_ERR_ARG with a message.
+ * Every call on a GPU shares that GPU's array: calls on one GPU that overlap in time (two handles, two threads) race. */
+#define AZ_STATIC_POP_SLOTS 256
+#define AZ_STATIC_POP_BYTES (8u << 20)
+int az_trajectory_pop_many_static(az_engine *h, const int32_t *slots, int32_t n, const int32_t *row_start, int32_t total_rows,
+                                  int16_t *moves, int32_t *visits, int32_t *winners, int32_t restart);
 
 /* ---- RNG (numpy.random.randint / random.gammavariate / random.choices) - */
 /* replay streams for one slot: transform ids, gamma draws, move-choice uniforms */
