@@ -100,6 +100,7 @@ SIGNATURES = {
     "az_search_root_stats_f64": (_I, [_P, _I, _I, _P, _P, _P, _P, _P]),
     "az_tower_load_weights_net": (_I, [_P, _I, _P, C.c_size_t]),
     "az_match_assign": (_I, [_P, _P, _I, _P]),
+    "az_match_leaf_nets": (_I, [_P, _P]),
     "az_tower_forward": (_I, [_P, _P, _I, _P, _P]),
     "az_tower_forward_dev": (_I, [_P, _P, _I, _P, _P]),
     "az_tower_flops_per_eval": (C.c_double, [_P]),

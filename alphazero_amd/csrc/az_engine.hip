@@ -49,6 +49,7 @@ struct az_engine {
     bool compact = true;  // run the tower only on the leaf rows that need it, when its kernels can take the count from the device
     int32_t *net_first = nullptr, *net_rows = nullptr, *net_cnt = nullptr;  // [G], [2][G], [2]
     unsigned long long *net_tot = nullptr;  // [2] boards each network has evaluated, summed on the device
+    unsigned long long *net_tot_spare = nullptr;  // [2] sink for the totals of az_match_leaf_nets' extra split
     int16_t *pop_moves = nullptr;   // staging of az_trajectory_pop_many, grown on demand
     int32_t *pop_visits = nullptr;
     size_t pop_rows = 0;
@@ -240,7 +241,8 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     ok = ok && (h->st_a = dalloc<int32_t>(h, stn)) && (h->st_b = dalloc<int32_t>(h, stn)) &&
          (h->st_c = dalloc<int32_t>(h, stn)) && (h->st_d = dalloc<int32_t>(h, stn)) && (h->st_e = dalloc<int32_t>(h, stn));
     ok = ok && (h->net_first = dalloc<int32_t>(h, G)) && (h->net_rows = dalloc<int32_t>(h, 2 * (size_t)G * std::max(1, (int)cfg->leaves_per_round))) &&
-         (h->net_cnt = dalloc<int32_t>(h, 2)) && (h->net_tot = dalloc<unsigned long long>(h, 2));
+         (h->net_cnt = dalloc<int32_t>(h, 2)) && (h->net_tot = dalloc<unsigned long long>(h, 2)) &&
+         (h->net_tot_spare = dalloc<unsigned long long>(h, 2));
     h->st_bytes_n = (size_t)G * std::max(O, 17 * NC);
     ok = ok && (h->st_bytes = dalloc<uint8_t>(h, h->st_bytes_n));
     if (!ok) {
@@ -1074,6 +1076,33 @@ extern "C" int az_match_assign(az_engine *h, const int32_t *slots, int32_t n, co
         HIPCHK(hipMemcpy(h->net_first + slots[i], net_of_first + i, sizeof(int32_t), hipMemcpyHostToDevice));
     }
     h->two_nets = true;
+    return AZ_OK;
+}
+
+extern "C" int az_match_leaf_nets(az_engine *h, int32_t *net_of_slot)
+{
+    if (!h || !net_of_slot) return AZ_ERR_ARG;
+    if (!h->two_nets) return set_err(h, AZ_ERR_STATE, "no match assignment is in force (az_match_assign)");
+    if (h->D.K > 1) return set_err(h, AZ_ERR_ARG, "two-network matches run one leaf per tree per round (leaves_per_round = 1)");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int G = h->D.G;
+    // the same split the tower path launches in evaluate(); the running totals go to a spare pair of words
+    hipLaunchKernelGGL(k_partition, dim3(1), dim3(1024), 0, h->stream, h->D, (const int32_t *)h->net_first, h->net_rows, h->net_cnt,
+                       h->net_tot_spare);
+    std::vector<int32_t> rows(2 * (size_t)G);
+    int32_t cnt[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(rows.data(), h->net_rows, sizeof(int32_t) * rows.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(cnt, h->net_cnt, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int g = 0; g < G; g++) net_of_slot[g] = -1;
+    for (int net = 0; net < 2; net++) {
+        if (cnt[net] < 0 || cnt[net] > G) return set_err(h, AZ_ERR_HIP, "leaf partition returned a bad count");
+        for (int i = 0; i < cnt[net]; i++) {
+            const int g = rows[(size_t)net * G + i];
+            if (g < 0 || g >= G || net_of_slot[g] != -1) return set_err(h, AZ_ERR_HIP, "leaf partition lists a slot twice or out of range");
+            net_of_slot[g] = net;
+        }
+    }
     return AZ_OK;
 }
 

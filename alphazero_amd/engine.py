@@ -276,6 +276,12 @@ class Engine:
         nf = np.ascontiguousarray(net_of_first, np.int32)
         self._ck(self._L.az_match_assign(self._h, s.ctypes.data if s.size else None, s.size, nf.ctypes.data if nf.size else None))
 
+    def match_leaf_nets(self):
+        """Network (0 / 1) that evaluates this round's leaf of every slot, -1 where no evaluation is needed."""
+        out = np.zeros(self.G, np.int32)
+        self._ck(self._L.az_match_leaf_nets(self._h, out.ctypes.data))
+        return out
+
     def tower_forward(self, planes):
         x = np.ascontiguousarray(planes, np.int8)
         B = x.shape[0]

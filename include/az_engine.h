@@ -235,6 +235,12 @@ int az_search_root_stats_f64(az_engine *h, int32_t slot, int32_t side, int32_t *
  * with NULL priors route every leaf to the network owning the searching tree.  n = 0 returns to one network. */
 int az_tower_load_weights_net(az_engine *h, int32_t net, const float *blob, size_t n_floats);
 int az_match_assign(az_engine *h, const int32_t *slots, int32_t n, const int32_t *net_of_first);
+/* Which network evaluates this round's leaf of every slot, for a caller that computes the priors itself
+ * (az_selfplay_select -> az_leaf_batch -> here -> az_selfplay_finish(priors, values)): net_of_slot[n_slots] = 0 / 1, or -1
+ * for a slot whose leaf needs no evaluation (idle, or a finished game below the root).  Runs the same device-side split
+ * as the tower path and returns its lists, i.e. nn_eval_1 / nn_eval_2 of Game(nn_eval_1, nn_eval_2, ...) by side to move
+ * (game/gameplay.py:19-20, 62-65). */
+int az_match_leaf_nets(az_engine *h, int32_t *net_of_slot);
 /* x int8 (B,17,H,W) host; out_p (B,O), out_v (B) float32 host */
 int az_tower_forward(az_engine *h, const int8_t *planes, int32_t B, float *out_p, float *out_v);
 /* the same with all three arrays already in this GPU's memory (e.g. torch.Tensor.data_ptr()); returns after the

@@ -653,6 +653,127 @@ int oz_tree_search(OzTree *t, const OzState *s, int max_playout, int dirichlet,
     return evals;
 }
 
+/* ------------------------------------------------------------------ */
+/* Several leaves per round under a virtual loss.  NOT in the reference (mcts.py:295-296 keeps one playout in
+ * flight): this is the definition of the engine's opt-in `leaves_per_round = K > 1` schedule, restated in scalar
+ * code so that the engine's trees can be held to something other than themselves.
+ *
+ * A search = root.visit(); root expansion if the root is a leaf (raw value, then noise) or noise on the existing
+ * children; then rounds until max_playout playouts have been issued.  One round:
+ *   select, j = 0 .. min(K, playouts left) - 1, one after the other: a playout descends from the root on the
+ *     statistics as they stand (including the virtual losses of the round's earlier playouts); every node it enters
+ *     is visited (N += 1) at once and every edge it takes loses `vloss` from W; its transform id is drawn before the
+ *     descent; the leaf's state, legality and end-of-game status are taken now;
+ *   evaluate the round's leaves;
+ *   finish, j in the same order: a leaf that an earlier playout of the round has expanded meanwhile is not
+ *     expanded again (its value is only backed up); otherwise expand / terminal value as in mcts.py:217-231; the
+ *     leaf and every edge of the path get their W update as `W += (-player * v) + vloss` (the root, which never took
+ *     a virtual loss, `W += -player * v`).
+ * With K = 1 and vloss = 0 this is mcts.py's schedule. */
+/* ------------------------------------------------------------------ */
+
+typedef struct {
+    int node, depth, tid, terminal, winner, cur, n_legal;
+    int path_node[OZ_KMAXD];
+    int path_player[OZ_KMAXD];
+    uint8_t legal[OZ_MAXO];
+    int8_t planes[OZ_NPLANES * OZ_MAXC];
+    oz_real pri[OZ_MAXO], value;
+} OzLeaf;
+
+int oz_tree_search_k(OzTree *t, const OzState *s, int max_playout, int K, double vloss, int dirichlet,
+                     oz_eval_fn ev, void *ctx, OzRng *rng)
+{
+    if (K < 1) K = 1;
+    const oz_real vl = K > 1 ? (oz_real)vloss : (oz_real)0.0;
+    const int enable = !(t->transform_types == 0 || t->transform_types == 1);
+    int evals = 0;
+    t->nodes[t->root].n++;
+    if (t->nodes[t->root].cnt == 0) {
+        int acts[OZ_MAXO];
+        oz_real probs[OZ_MAXO], value;
+        int n = eval_candidates(t, s, ev, ctx, rng, acts, probs, &value);
+        tree_expand(t, t->root, acts, probs, n, value);
+        evals++;
+    }
+    if (dirichlet) {
+        OzNode *r = &t->nodes[t->root];
+        oz_real keep = (oz_real)(1.0 - t->d_epsilon);
+        for (int i = 0; i < r->cnt; i++) {
+            double eta = rng_eta(rng, t->d_alpha);
+            OzNode *c = &t->nodes[r->first + i];
+            oz_real a = keep * c->p;
+            c->p = a + (oz_real)(t->d_epsilon * eta);
+        }
+    }
+    OzLeaf *lv = (OzLeaf *)malloc(sizeof(OzLeaf) * (size_t)K);
+    int issued = 0;
+    while (issued < max_playout) {
+        const int m = max_playout - issued < K ? max_playout - issued : K;
+        for (int j = 0; j < m; j++) {               /* select */
+            OzLeaf *L = &lv[j];
+            OzState c;
+            oz_copy(&c, s);
+            L->tid = enable ? rng_tid(rng, t->transform_types) : 0;
+            int node = t->root;
+            t->nodes[node].n++;
+            L->depth = 0;
+            while (t->nodes[node].cnt != 0) {
+                int ch = tree_select(t, node);
+                if (L->depth >= OZ_KMAXD) { free(lv); return -2; }
+                L->path_node[L->depth] = node;
+                L->path_player[L->depth] = c.cur;
+                L->depth++;
+                oz_do_move(&c, t->nodes[ch].action);
+                t->nodes[ch].n++;
+                if (K > 1) t->nodes[ch].w -= vl;
+                node = ch;
+            }
+            issued++;
+            L->node = node;
+            L->cur = c.cur;
+            L->n_legal = 0;
+            for (int a = 0; a < c.O; a++) { L->legal[a] = (uint8_t)oz_is_legal(&c, a); L->n_legal += L->legal[a]; }
+            L->terminal = (L->n_legal == 0) || c.is_end;
+            L->winner = L->terminal ? oz_winner(&c) : 0;
+            oz_features(&c, L->tid, L->planes);
+        }
+        for (int j = 0; j < m; j++) {               /* evaluate */
+            ev(ctx, lv[j].planes, s->H, s->W, s->O, lv[j].pri, &lv[j].value);
+            evals++;
+        }
+        for (int j = 0; j < m; j++) {               /* finish */
+            OzLeaf *L = &lv[j];
+            oz_real v = L->value;
+            const int is_root = L->node == t->root;
+            if (!L->terminal && t->nodes[L->node].cnt != 0) {
+                oz_real add = (oz_real)(-L->cur) * v;
+                if (is_root) t->nodes[L->node].w += add; else t->nodes[L->node].w += add + vl;
+            } else if (!L->terminal) {
+                int acts[OZ_MAXO], n = 0;
+                oz_real probs[OZ_MAXO];
+                for (int i = 0; i < s->O; i++) {
+                    int a = enable ? oz_reverse_label(i, s->H, s->W, L->tid) : i;
+                    if (L->legal[a]) { acts[n] = a; probs[n] = L->pri[i]; n++; }
+                }
+                oz_real add = (oz_real)(-L->cur) * v;
+                tree_expand(t, L->node, acts, probs, n, is_root ? add : add + vl);
+            } else {
+                v = (oz_real)L->winner;
+                oz_real add = (oz_real)(-L->cur) * v;
+                if (is_root) t->nodes[L->node].w += add; else t->nodes[L->node].w += add + vl;
+            }
+            for (int d = 0; d < L->depth; d++) {
+                oz_real add = (oz_real)(-L->path_player[d]) * v;
+                if (L->path_node[d] == t->root) t->nodes[L->path_node[d]].w += add;
+                else t->nodes[L->path_node[d]].w += add + vl;
+            }
+        }
+    }
+    free(lv);
+    return evals;
+}
+
 int oz_tree_root_stats(const OzTree *t, int32_t *actions, int32_t *visits, oz_real *W, oz_real *P)
 {
     const OzNode *r = &t->nodes[t->root];
@@ -744,21 +865,27 @@ int oz_tree_count_expanded(const OzTree *t)
 /* gameplay (AlphaZero/game/gameplay.py:38-94)                        */
 /* ------------------------------------------------------------------ */
 
-int oz_play_game(const OzGameCfg *cfg, oz_eval_fn ev, void *ctx, OzRng *rng,
-                 OzTrajectory *traj, int max_plies)
+/* Game(nn_eval_1, nn_eval_2, ...): player_1 (Black, moves first) searches with ev1, player_2 with ev2
+ * (gameplay.py:19-20; train/parallel/evaluator.py:81-85 passes two different evaluators).  K > 1 searches with
+ * oz_tree_search_k instead of the reference's schedule. */
+int oz_play_game_ex(const OzGameCfg *cfg, oz_eval_fn ev1, void *ctx1, oz_eval_fn ev2, void *ctx2, int K, double vloss,
+                    OzRng *rng, OzTrajectory *traj, int max_plies)
 {
     OzState st;
     oz_init(&st, cfg->game, cfg->H, cfg->W, cfg->k);
     OzTree *tr[2];
     tr[0] = oz_tree_new(st.O, cfg->transform_types, cfg->d_alpha, cfg->d_epsilon);
     tr[1] = oz_tree_new(st.O, cfg->transform_types, cfg->d_alpha, cfg->d_epsilon);
+    oz_eval_fn evs[2] = {ev1, ev2};
+    void *ctxs[2] = {ctx1, ctx2};
     int cur = 0, ply = 0;
     int32_t acts[OZ_MAXO], vis[OZ_MAXO];
     traj->n_evals = 0;
     while (!(st.is_end || st.turns > cfg->max_turn)) {
         if (ply >= max_plies) break;
-        traj->n_evals += oz_tree_search(tr[cur], &st, cfg->max_playout,
-                                        st.turns <= cfg->dirichlet_before, ev, ctx, rng);
+        const int noise = st.turns <= cfg->dirichlet_before;
+        if (K > 1) traj->n_evals += oz_tree_search_k(tr[cur], &st, cfg->max_playout, K, vloss, noise, evs[cur], ctxs[cur], rng);
+        else traj->n_evals += oz_tree_search(tr[cur], &st, cfg->max_playout, noise, evs[cur], ctxs[cur], rng);
         int n = oz_tree_root_stats(tr[cur], acts, vis, NULL, NULL);
         int move = oz_tree_choose(tr[cur], rng_uni(rng));
         if (traj->visits) {
@@ -780,6 +907,12 @@ int oz_play_game(const OzGameCfg *cfg, oz_eval_fn ev, void *ctx, OzRng *rng,
     return rng->underflow ? -1 : 0;
 }
 
+int oz_play_game(const OzGameCfg *cfg, oz_eval_fn ev, void *ctx, OzRng *rng,
+                 OzTrajectory *traj, int max_plies)
+{
+    return oz_play_game_ex(cfg, ev, ctx, ev, ctx, 1, 0.0, rng, traj, max_plies);
+}
+
 /* ------------------------------------------------------------------ */
 /* evaluators used by tests / baseline                                */
 /* ------------------------------------------------------------------ */
@@ -795,11 +928,13 @@ static inline uint64_t mix64(uint64_t z)
  * float32 priors in (0, 4/O] and a float32 value in [-0.5, 0.5). */
 void oz_fake_eval(void *ctx, const int8_t *planes, int H, int W, int O, oz_real *priors, oz_real *value)
 {
-    (void)ctx;
+    /* ctx: NULL, or a uint64 salt that makes a second, different "network" (0 = the unsalted one) */
+    const uint64_t salt = ctx ? *(const uint64_t *)ctx : 0;
     uint64_t h = 0;
     int n = OZ_NPLANES * H * W;
     for (int j = 0; j < n; j++)
         h += (uint64_t)(uint8_t)planes[j] * mix64((uint64_t)(j + 1) * 0x9E3779B97F4A7C15ULL);
+    if (salt) h ^= mix64(salt);
     float scale = (float)(4.0 / (double)O);
     for (int i = 0; i < O; i++) {
         uint64_t z = mix64(h + (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ULL);

@@ -123,6 +123,13 @@ typedef struct {
 
 int oz_play_game(const OzGameCfg *cfg, oz_eval_fn ev, void *ctx, OzRng *rng,
                  OzTrajectory *traj, int max_plies);
+/* two evaluators (player_1 = ev1 moves first) and, with K > 1, the several-leaves-per-round schedule */
+int oz_play_game_ex(const OzGameCfg *cfg, oz_eval_fn ev1, void *ctx1, oz_eval_fn ev2, void *ctx2, int K, double vloss,
+                    OzRng *rng, OzTrajectory *traj, int max_plies);
+/* K leaves per round under a virtual loss: the engine's opt-in schedule restated (not in the reference) */
+#define OZ_KMAXD 1024
+int oz_tree_search_k(OzTree *t, const OzState *s, int max_playout, int K, double vloss, int dirichlet,
+                     oz_eval_fn ev, void *ctx, OzRng *rng);
 
 /* deterministic hash evaluator shared with the fixture generator */
 void oz_fake_eval(void *ctx, const int8_t *planes, int H, int W, int O,

@@ -41,12 +41,15 @@ def position_hash(planes):
         return (flat * _coefs(flat.shape[-1])).sum(axis=-1, dtype=np.uint64)
 
 
-def fake_eval_planes(planes, O):
-    """planes int8 (B, F, H, W) or (F, H, W) -> (priors float32 (B,O), values float32 (B,))."""
+def fake_eval_planes(planes, O, salt=0):
+    """planes int8 (B, F, H, W) or (F, H, W) -> (priors float32 (B,O), values float32 (B,)).
+    salt != 0 gives a second, different "network" (two-evaluator games)."""
     single = planes.ndim == 3
     if single:
         planes = planes[None]
     h = position_hash(planes)  # (B,)
+    if salt:
+        h = h ^ _mix64(np.uint64(salt))
     with np.errstate(over="ignore"):
         i = np.arange(1, O + 1, dtype=np.uint64) * _G
         z = _mix64(h[:, None] + i[None, :])

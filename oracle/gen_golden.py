@@ -183,8 +183,9 @@ class FakeEvaluator:
     """eval(state) -> ([(action, np.float32)], np.float32): the evaluator contract of
     evaluator/nn_eval_parallel.py:75-92 with the network replaced by a hash."""
 
-    def __init__(self, cfg, real64=None):
+    def __init__(self, cfg, real64=None, salt=0):
         self.cfg = cfg
+        self.salt = salt      # != 0: a second, different "network" (two-evaluator games)
         self.conv = sc.StateTensorConverter(cfg)
         self.t2a = sc.TensorActionConverter(cfg)
         self.calls = 0
@@ -196,7 +197,7 @@ class FakeEvaluator:
         if self.real64 == "uniform":  # evaluator/dummy_eval.py:26-28: np.full float64 priors, Python int 0
             dims = self.cfg["flat_move_output"]
             return self.t2a.tensor_to_action(np.full((dims,), 1 / dims)), 0
-        pri, v = fake_eval_planes(planes, self.cfg["flat_move_output"])
+        pri, v = fake_eval_planes(planes, self.cfg["flat_move_output"], self.salt)
         assert pri.dtype == np.float32 and isinstance(v, np.float32)
         if self.real64 == "fake":
             return self.t2a.tensor_to_action(pri.astype(np.float64)), float(v)
@@ -259,12 +260,14 @@ def root_record(search, H, W, O, real64=False):
 
 
 def search_trace(name, game, H, W, k, transform_types, max_playout, dirichlet_before, max_turn,
-                 seed, ply_limit, use_game_class=False, real64=None):
+                 seed, ply_limit, use_game_class=False, real64=None, salts=None):
     cfg = cfg_for(game, H, W, transform_types, k)
     O = cfg["flat_move_output"]
     streams = Streams(seed)
     install_rng_hooks(streams)
-    ev = FakeEvaluator(cfg, real64)
+    ev = FakeEvaluator(cfg, real64, salts[0] if salts else 0)
+    # Game(nn_eval_1, nn_eval_2, ...) with two different evaluators: train/parallel/evaluator.py:81-85
+    ev2 = FakeEvaluator(cfg, real64, salts[1]) if salts else ev
     ext = {"player": {"max_playout": max_playout}, "dirichlet_before": dirichlet_before,
            "log_iter": 10 ** 9, "max_turn": max_turn}
     recs = []
@@ -278,7 +281,8 @@ def search_trace(name, game, H, W, k, transform_types, max_playout, dirichlet_be
             recs.append(dict(n=n, acts=acts, N=N, W=Wv, P=P, rootN=rootN, move=a2i(move, H, W),
                              dirichlet=int(bool(dirichlet)), n_tids=len(streams.tids),
                              n_etas=len(streams.etas), n_unis=len(streams.unis),
-                             board=np.array(state.board, np.int8), evals=ev.calls))
+                             board=np.array(state.board, np.int8),
+                             evals=ev.calls + (ev2.calls if ev2 is not ev else 0)))
             return move, probs
         return _think
 
@@ -287,13 +291,13 @@ def search_trace(name, game, H, W, k, transform_types, max_playout, dirichlet_be
     hist = None
     try:
         if use_game_class:
-            g = gameplay.Game(ev, ev, cfg, ext)
+            g = gameplay.Game(ev, ev2, cfg, ext)
             winner = g.start()
             hist = g.get_history()
             final_state = g.state
         else:
             p1 = mcts_player.Player(ev, cfg, ext["player"])
-            p2 = mcts_player.Player(ev, cfg, ext["player"])
+            p2 = mcts_player.Player(ev2, cfg, ext["player"])
             st = make_state(game, H, W, k)
             cur = p1
             ply = 0
@@ -329,7 +333,8 @@ def search_trace(name, game, H, W, k, transform_types, max_playout, dirichlet_be
         cum_evals=np.array([r["evals"] for r in recs], np.int64),
         boards=np.array([r["board"] for r in recs], np.int8),
         final_board=np.array(final_state.board, np.int8),
-        winner=2 if winner is None else int(winner), total_evals=ev.calls,
+        winner=2 if winner is None else int(winner), total_evals=ev.calls + (ev2.calls if ev2 is not ev else 0),
+        salts=np.array(salts if salts else (0, 0), np.uint64),
     )
     if hist is not None:
         out["hist_state"] = hist[0].astype(np.int8)
@@ -392,9 +397,23 @@ def main_shapes():
     save("search_go5_maxturn", d)
 
 
+def main_match():
+    """Games between two different evaluators, as the gating matches play them (train/parallel/evaluator.py:81-85:
+    Game(chal, best) when the challenger is Black, Game(best, chal) otherwise)."""
+    A, B = 0, 77
+    # (gameplay.Game builds GameState() with the module's default size, so the Game-class traces are 8x8 / 3x3)
+    save("match_reversi_ab", search_trace("m_rev_ab", "reversi", 8, 8, None, 8, 16, 30, 400, 81, 10 ** 9, use_game_class=True, salts=(A, B)))
+    save("match_reversi_ba", search_trace("m_rev_ba", "reversi", 8, 8, None, 8, 16, 30, 400, 81, 10 ** 9, use_game_class=True, salts=(B, A)))
+    save("match_go5_ab", search_trace("m_go5_ab", "go", 5, 5, None, 8, 24, 4, 30, 82, 10 ** 9, salts=(A, B)))
+    save("match_ttt_ba", search_trace("m_ttt_ba", "mnk", 3, 3, 3, 0, 50, 30, 400, 83, 10 ** 9, use_game_class=True, salts=(B, A)))
+    mnk.game_config.update(board_height=6, board_width=5, k=4)
+
+
 def main():
     if "--only64" in sys.argv:
         return main64()
+    if "--only-match" in sys.argv:
+        return main_match()
     if "--only-shapes" in sys.argv:
         return main_shapes()
     # ---- transforms: label tables of ReverseTransformer and forward board maps
@@ -468,7 +487,7 @@ def main():
     save("search_go9", search_trace("go9", "go", 9, 9, None, 8, 64, 30, 400, 26, 20))
     save("search_go19", search_trace("go19", "go", 19, 19, None, 8, 30, 30, 400, 27, 6))
     main64()
-    mnk.game_config.update(board_height=6, board_width=5, k=4)
+    main_match()
 
 
 if __name__ == "__main__":

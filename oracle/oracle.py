@@ -106,6 +106,10 @@ def lib(real64=False):
         L.oz_tree_count_expanded.argtypes = [C.c_void_p]
         L.oz_play_game.argtypes = [C.POINTER(OzGameCfg), C.c_void_p, C.c_void_p, C.POINTER(OzRng),
                                    C.POINTER(OzTrajectory), C.c_int]
+        L.oz_play_game_ex.argtypes = [C.POINTER(OzGameCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                                      C.POINTER(OzRng), C.POINTER(OzTrajectory), C.c_int]
+        L.oz_tree_search_k.argtypes = [C.c_void_p, SP, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.POINTER(OzRng)]
         L.oz_gamma_small_alpha.restype = C.c_double
         L.oz_gamma_small_alpha.argtypes = [C.c_double, C.POINTER(C.c_uint64)]
         _libs[real64] = L
@@ -215,6 +219,15 @@ class Tree:
         evp = ev if isinstance(ev, C.c_void_p) else C.cast(ev, C.c_void_p)
         return self.L.oz_tree_search(self.t, C.byref(state.s), max_playout, int(dirichlet), evp, None, C.byref(rng.r))
 
+    def search_k(self, state, max_playout, K, vloss, dirichlet, ev, rng, ctx=None):
+        """The several-leaves-per-round schedule (oz_tree_search_k)."""
+        evp = ev if isinstance(ev, C.c_void_p) else C.cast(ev, C.c_void_p)
+        rc = self.L.oz_tree_search_k(self.t, C.byref(state.s), max_playout, int(K), float(vloss), int(dirichlet), evp, ctx,
+                                     C.byref(rng.r))
+        if rc < 0:
+            raise RuntimeError("oracle: playout deeper than OZ_KMAXD")
+        return rc
+
     def playout(self, state, ev, rng):
         evp = ev if isinstance(ev, C.c_void_p) else C.cast(ev, C.c_void_p)
         self.L.oz_tree_playout(self.t, C.byref(state.s), evp, None, C.byref(rng.r))
@@ -234,7 +247,9 @@ class Tree:
 
 
 def play_game(game, H, W, k, transform_types, max_playout, dirichlet_before, max_turn,
-              ev, rng, d_alpha=0.03, d_epsilon=0.25, max_plies=None, real64=False):
+              ev, rng, d_alpha=0.03, d_epsilon=0.25, max_plies=None, real64=False, ev2=None, salts=None, K=1, vloss=1.0):
+    """One game.  ev2: evaluator of player_2 (default: the same as player_1's).  salts = (a, b): context words handed to
+    the two evaluators (oz_fake_eval reads a uint64 salt).  K > 1: several leaves per round (oz_tree_search_k)."""
     cfg = OzGameCfg(GAME_IDS.get(game, game), H, W, k, transform_types, max_playout,
                     dirichlet_before, max_turn, d_alpha, d_epsilon)
     O = H * W + (0 if GAME_IDS.get(game, game) == MNK else 1)
@@ -246,7 +261,14 @@ def play_game(game, H, W, k, transform_types, max_playout, dirichlet_before, max
     tr.moves = moves.ctypes.data_as(C.POINTER(C.c_int16))
     tr.visits = visits.ctypes.data_as(C.POINTER(C.c_int32))
     evp = ev if isinstance(ev, C.c_void_p) else C.cast(ev, C.c_void_p)
-    rc = lib(real64).oz_play_game(C.byref(cfg), evp, None, C.byref(rng.r), C.byref(tr), max_plies)
+    ev2 = ev if ev2 is None else ev2
+    evp2 = ev2 if isinstance(ev2, C.c_void_p) else C.cast(ev2, C.c_void_p)
+    ctx = [None, None]
+    if salts is not None:
+        keep = [C.c_uint64(int(salts[0])), C.c_uint64(int(salts[1]))]
+        ctx = [C.cast(C.pointer(keep[0]), C.c_void_p), C.cast(C.pointer(keep[1]), C.c_void_p)]
+    rc = lib(real64).oz_play_game_ex(C.byref(cfg), evp, ctx[0], evp2, ctx[1], int(K), float(vloss), C.byref(rng.r),
+                                     C.byref(tr), max_plies)
     if rc != 0:
         raise RuntimeError("oracle: RNG replay stream underflow")
     n = tr.n_plies

@@ -114,3 +114,95 @@ def test_leaf_compaction_changes_nothing_but_the_work(game, H, k, G, P, rounds, 
         assert np.array_equal(a["moves"], b["moves"]) and np.array_equal(a["visits"], b["visits"]) and a["winner"] == b["winner"]
     assert eb == rounds * G * K        # every row of every round
     assert ea < na <= eb               # only live, non-terminal leaves: fewer than the playouts counted
+
+
+def _fixture_engine(g, G):
+    from alphazero_amd.engine import Engine
+    return Engine(str(g["game"]), int(g["H"]), int(g["W"]), int(g["k"]), n_slots=G, max_playout=int(g["max_playout"]),
+                  transform_types=int(g["transform_types"]), dirichlet_before=int(g["dirichlet_before"]),
+                  max_turn=int(g["max_turn"]), d_alpha=float(g["d_alpha"]), d_epsilon=float(g["d_epsilon"]), rng_replay=True,
+                  record_trajectories=True)
+
+
+def _check_against_fixture(tr, g, O):
+    assert np.array_equal(tr["moves"], g["moves"]) and tr["winner"] == g["winner"]
+    for ply in range(len(g["moves"])):
+        nc = int(g["n_children"][ply])
+        exp = np.zeros(O, np.int32)
+        exp[g["acts"][ply][:nc]] = g["N"][ply][:nc]
+        assert np.array_equal(tr["visits"][ply], exp), ply
+
+
+@pytest.mark.parametrize("names", [("match_reversi_ab", "match_reversi_ba"), ("match_go5_ab",), ("match_ttt_ba",)])
+def test_match_assignment_against_reference_games(names):
+    """az_match_assign and the device-side leaf split held to games the reference played with two different evaluators
+    (Game(ev_a, ev_b, ...), fixtures match_*): the engine says which network owns each round's leaf
+    (az_match_leaf_nets, the lists its tower path uses), the test feeds that evaluator's priors, and moves, visit counts
+    and winners must be the reference's.  Slot i plays fixture i; a fixture recorded with the evaluators swapped runs
+    with net_of_first = 1."""
+    from oracle.fake_eval import fake_eval_planes
+    from tests.helpers import load_golden
+    gs = [load_golden(n) for n in names]
+    salts = [int(x) for x in gs[0]["salts"]]          # network 0 <-> salts[0], network 1 <-> salts[1]
+    G = len(gs)
+    eng = _fixture_engine(gs[0], G)
+    first = []
+    for s, g in enumerate(gs):
+        eng.rng_inject(s, g["tids"], g["etas"], g["unis"])
+        first.append(salts.index(int(g["salts"][0])))
+        assert salts[1 - first[-1]] == int(g["salts"][1])
+    eng.selfplay_start()
+    eng.match_assign(np.arange(G), first)
+    O = eng.O
+    while eng.selfplay_select() > 0:
+        planes, valid = eng.leaf_batch()
+        nets = eng.match_leaf_nets()
+        assert np.all((nets >= 0) <= (valid[:G] == 1))
+        pri = np.zeros((G, O), np.float32); val = np.zeros(G, np.float32)
+        for s in range(G):
+            if nets[s] >= 0:
+                pri[s], val[s] = fake_eval_planes(planes[s], O, salts[nets[s]])
+            else:                                      # a finished game below the root: the answer is never read
+                pri[s], val[s] = np.nan, np.nan
+        eng.selfplay_finish(pri, val)
+    plies, done = eng.selfplay_status()
+    assert np.all(done == 1)
+    for s, g in enumerate(gs):
+        _check_against_fixture(eng.trajectory_pop(s), g, O)
+    eng.close()
+
+
+def test_match_assignment_against_oracle_many_slots():
+    """The same through 40 slots with mixed assignments and their own draws, against oz_play_game_ex."""
+    from alphazero_amd.engine import Engine
+    from oracle import oracle as oz
+    from oracle.fake_eval import fake_eval_planes
+    H, P, mt, G = 6, 12, 40, 40
+    salts = (5, 99)
+    rng = np.random.RandomState(3)
+    eng = Engine("reversi", H, H, n_slots=G, max_playout=P, transform_types=8, dirichlet_before=6, max_turn=mt, rng_replay=True,
+                 record_trajectories=True)
+    O = eng.O
+    streams = []
+    for s in range(G):
+        st = (rng.randint(0, 8, size=(mt + 2) * (P + 1)).astype(np.int32), rng.gamma(0.03, 1.0, size=(mt + 2) * O), rng.rand(mt + 2))
+        streams.append(st)
+        eng.rng_inject(s, *st)
+    first = rng.randint(0, 2, size=G).astype(np.int32)
+    eng.selfplay_start()
+    eng.match_assign(np.arange(G), first)
+    while eng.selfplay_select() > 0:
+        planes, valid = eng.leaf_batch()
+        nets = eng.match_leaf_nets()
+        pri = np.full((G, O), np.nan, np.float32); val = np.full(G, np.nan, np.float32)
+        for net in (0, 1):
+            rows = np.flatnonzero(nets == net)
+            if rows.size:
+                pri[rows], val[rows] = fake_eval_planes(planes[rows], O, salts[net])
+        eng.selfplay_finish(pri, val)
+    for s in range(G):
+        a, b = salts[first[s]], salts[1 - first[s]]
+        ref = oz.play_game("reversi", H, H, 0, 8, P, 6, mt, oz.fn_ptr("oz_fake_eval"), oz.Rng(*streams[s]), salts=(a, b))
+        tr = eng.trajectory_pop(s)
+        assert np.array_equal(tr["moves"], ref["moves"]) and np.array_equal(tr["visits"], ref["visits"]) and tr["winner"] == ref["winner"], s
+    eng.close()

@@ -251,6 +251,67 @@ def test_several_leaves_per_round_keep_the_tree_consistent(K, vloss):
     eng.close()
 
 
+@pytest.mark.parametrize("game,H,k,tt,K,vloss,P", [("go", 7, 0, 8, 4, 1.0, 150), ("go", 9, 0, 8, 16, 0.5, 203), ("reversi", 8, 0, 8, 8, 1.0, 96),
+                                                   ("mnk", 5, 4, 0, 3, 0.25, 40), ("go", 19, 0, 8, 32, 1.0, 320)])
+def test_several_leaves_per_round_against_scalar_restatement(game, H, k, tt, K, vloss, P):
+    """leaves_per_round = K under a virtual loss is not the reference's schedule (it keeps one playout in flight); its
+    definition is the scalar oz_tree_search_k of the oracle (which with K = 1 is pinned to the reference's trees).  Two
+    consecutive searches of one tree with a re-root in between: child order, N, and the bit patterns of W and P."""
+    from alphazero_amd.engine import Engine
+    rng = np.random.RandomState(K * 100 + H)
+    eng = Engine(game, H, H, k, n_slots=2, max_playout=P, transform_types=tt, leaves_per_round=K, virtual_loss=vloss,
+                 rng_replay=True, dirichlet_before=30)
+    O = eng.O
+    tids = rng.randint(0, 8, size=4 * (P + 2)).astype(np.int32)
+    etas = rng.gamma(0.03, 1.0, size=4 * O)
+    eng.rng_inject(1, tids, etas, [])
+    st = oz.State(game, H, H, k)
+    tree = oz.Tree(O, tt)
+    orng = oz.Rng(tids, etas, [])
+    for search in range(2):
+        eng.search_begin([1], [0], [1])
+        while eng.step_select() > 0:
+            planes, valid = eng.leaf_batch()
+            assert planes.shape[0] == 2 * K
+            pri, v = fake_eval_planes(planes, O)
+            eng.step_finish(pri, v)
+        tree.search_k(st, P, K, vloss, True, oz.fn_ptr("oz_fake_eval"), orng)
+        a, n, w, p, rootN = eng.root_stats(1, 0)
+        ra, rn, rw, rp = tree.root_stats()
+        assert rootN == tree.root_visits()
+        assert np.array_equal(a, ra) and np.array_equal(n, rn)
+        assert np.array_equal(w.view(np.uint32), rw.view(np.uint32)) and np.array_equal(p.view(np.uint32), rp.view(np.uint32))
+        assert eng.rng_cursor(1)[:2] == (orng.r.i_tids, orng.r.i_etas)
+        mv = int(a[int(np.argmax(n))])
+        eng.do_move([1], [mv]); eng.advance_tree(1, 0, mv)
+        st.do_move(mv); tree.update_with_move(mv)
+    eng.close()
+
+
+def test_selfplay_several_leaves_per_round_against_scalar_restatement():
+    """Whole games of the device-side self-play machine at K = 4 against oz_play_game_ex with the same schedule."""
+    from alphazero_amd.engine import Engine
+    game, H, P, db, mt, G, K, vl = "go", 5, 30, 6, 24, 6, 4, 1.0
+    rng = np.random.RandomState(77)
+    eng = Engine(game, H, H, n_slots=G, max_playout=P, transform_types=8, dirichlet_before=db, max_turn=mt, rng_replay=True,
+                 record_trajectories=True, leaves_per_round=K, virtual_loss=vl)
+    O = eng.O
+    streams = []
+    for s in range(G):
+        st = (rng.randint(0, 8, size=(mt + 2) * (P + 1)).astype(np.int32), rng.gamma(0.03, 1.0, size=(mt + 2) * O), rng.rand(mt + 2))
+        streams.append(st)
+        eng.rng_inject(s, *st)
+    eng.selfplay_start()
+    _selfplay_injected(eng)
+    plies, done = eng.selfplay_status()
+    assert np.all(done == 1)
+    for s in range(G):
+        ref = oz.play_game(game, H, H, 0, 8, P, db, mt, oz.fn_ptr("oz_fake_eval"), oz.Rng(*streams[s]), K=K, vloss=vl)
+        tr = eng.trajectory_pop(s)
+        assert np.array_equal(tr["moves"], ref["moves"]) and np.array_equal(tr["visits"], ref["visits"]) and tr["winner"] == ref["winner"], s
+    eng.close()
+
+
 def test_selfplay_with_several_leaves_per_round():
     from alphazero_amd.engine import Engine
     from alphazero_amd.network.model import fold_to_blob, random_net

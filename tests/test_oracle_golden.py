@@ -148,6 +148,81 @@ def test_play_game_and_history(name):
         st.do_move(int(tr["moves"][i]))
 
 
+@pytest.mark.parametrize("name", golden_names("match_"))
+def test_two_evaluator_game(name):
+    """Game(nn_eval_1, nn_eval_2, ...) with two different evaluators (train/parallel/evaluator.py:81-85): the oracle's
+    oz_play_game_ex against games the reference played, per ply visit counts included."""
+    g = load_golden(name)
+    game, H, W, k, O = str(g["game"]), int(g["H"]), int(g["W"]), int(g["k"]), int(g["O"])
+    assert g["salts"][0] != g["salts"][1]
+    rng = oz.Rng(tids=g["tids"], etas=g["etas"], unis=g["unis"])
+    tr = oz.play_game(game, H, W, k, int(g["transform_types"]), int(g["max_playout"]), int(g["dirichlet_before"]),
+                      int(g["max_turn"]), oz.fn_ptr("oz_fake_eval"), rng, float(g["d_alpha"]), float(g["d_epsilon"]),
+                      salts=g["salts"])
+    assert np.array_equal(tr["moves"], g["moves"]) and tr["winner"] == g["winner"] and tr["n_evals"] == g["total_evals"]
+    for ply in range(len(g["moves"])):
+        nc = int(g["n_children"][ply])
+        exp = np.zeros(O, np.int32)
+        exp[g["acts"][ply][:nc]] = g["N"][ply][:nc]
+        assert np.array_equal(tr["visits"][ply], exp), ply
+    # the salt matters: the same draws with one evaluator on both sides play a different game
+    same = oz.play_game(game, H, W, k, int(g["transform_types"]), int(g["max_playout"]), int(g["dirichlet_before"]),
+                        int(g["max_turn"]), oz.fn_ptr("oz_fake_eval"), oz.Rng(seed=3), float(g["d_alpha"]), float(g["d_epsilon"]),
+                        salts=(int(g["salts"][0]), int(g["salts"][0])))
+    other = oz.play_game(game, H, W, k, int(g["transform_types"]), int(g["max_playout"]), int(g["dirichlet_before"]),
+                         int(g["max_turn"]), oz.fn_ptr("oz_fake_eval"), oz.Rng(seed=3), float(g["d_alpha"]), float(g["d_epsilon"]),
+                         salts=g["salts"])
+    assert not (np.array_equal(same["moves"], other["moves"]) and np.array_equal(same["visits"], other["visits"]))
+
+
+def test_salted_fake_eval_c_matches_numpy():
+    rng = np.random.RandomState(1)
+    planes = rng.randint(0, 2, size=(17, 5, 5)).astype(np.int8)
+    for salt in (0, 77, 2 ** 63 + 5):
+        pr = np.zeros(26, np.float32); v = np.zeros(1, np.float32)
+        ctx = oz.C.c_uint64(salt)
+        oz.lib().oz_fake_eval(oz.C.byref(ctx), planes.ctypes.data_as(oz.C.POINTER(oz.C.c_int8)), 5, 5, 26,
+                              pr.ctypes.data_as(oz.C.POINTER(oz.C.c_float)), v.ctypes.data_as(oz.C.POINTER(oz.C.c_float)))
+        p2, v2 = fake_eval_planes(planes, 26, salt)
+        assert np.array_equal(pr, p2) and v[0] == v2
+    assert not np.array_equal(fake_eval_planes(planes, 26, 0)[0], fake_eval_planes(planes, 26, 77)[0])
+
+
+@pytest.mark.parametrize("name", ["search_go5_game", "search_reversi_game", "search_ttt_game"])
+def test_k_leaf_schedule_with_one_leaf_is_the_reference(name):
+    """oz_tree_search_k (the several-leaves-per-round schedule the engine offers) with K = 1 is mcts.py's schedule:
+    same trees as the fixtures recorded from the reference, W and P bit for bit."""
+    g = load_golden(name)
+    game, H, W, k, O = str(g["game"]), int(g["H"]), int(g["W"]), int(g["k"]), int(g["O"])
+    rng = oz.Rng(tids=g["tids"], etas=g["etas"], unis=g["unis"])
+    st = oz.State(game, H, W, k)
+    trees = [oz.Tree(O, int(g["transform_types"]), float(g["d_alpha"]), float(g["d_epsilon"])) for _ in range(2)]
+    cur = 0
+    for ply in range(len(g["moves"])):
+        trees[cur].search_k(st, int(g["max_playout"]), 1, 1.0, st.s.turns <= int(g["dirichlet_before"]), oz.fn_ptr("oz_fake_eval"), rng)
+        a, n, w, p = trees[cur].root_stats()
+        nc = int(g["n_children"][ply])
+        assert np.array_equal(a, g["acts"][ply][:nc]) and np.array_equal(n, g["N"][ply][:nc]), ply
+        assert np.array_equal(w.view(np.uint32), g["Wv"][ply][:nc].view(np.uint32)), ply
+        assert np.array_equal(p.view(np.uint32), g["P"][ply][:nc].view(np.uint32)), ply
+        mv = trees[cur].choose(float(g["unis"][rng.r.i_unis])); rng.r.i_unis += 1
+        assert mv == g["moves"][ply]
+        st.do_move(mv)
+        trees[0].update_with_move(mv); trees[1].update_with_move(mv)
+        cur ^= 1
+
+
+def test_k_leaf_schedule_properties():
+    """K > 1: the budget is met exactly, every playout is one visit, no virtual loss is left on any root edge."""
+    st = oz.State("go", 7, 7)
+    for K, vl in ((4, 1.0), (16, 0.5)):
+        t = oz.Tree(50, 8)
+        n_ev = t.search_k(st, 203, K, vl, True, oz.fn_ptr("oz_fake_eval"), oz.Rng(seed=9))
+        a, n, w, p = t.root_stats()
+        assert n_ev == 204 and t.root_visits() == 204 and n.sum() == 203
+        assert np.all(np.abs(w) <= 0.5 * n + 1e-4)
+
+
 # ---- the reference's own known-answer tests, restated on the oracle -------------
 
 def _dummy_policy_eval(planes, O):
