@@ -82,6 +82,7 @@ SIGNATURES = {
     "az_search_advance_tree": (_I, [_P, _I, _I, _I]),
     "az_search_advance": (_I, [_P, _P, _I, _P]),
     "az_search_tree_size": (_I, [_P, _I, _I, _P, _P]),
+    "az_search_grow_trees": (_I, [_P, _I, _I]),
     "az_selfplay_start": (_I, [_P]),
     "az_selfplay_run": (_I, [_P, _I]),
     "az_selfplay_select": (_I, [_P, _P]),

@@ -117,6 +117,66 @@ static int check_slot_errors(az_engine *h)
     return AZ_OK;
 }
 
+// Enlarges the arenas of every tree to new_ec edges / new_bc expanded nodes (never shrinks): new arrays, each tree's
+// old stride copied to the front of its new one, old arrays freed.  The stream is idle on entry and on return.
+static int grow_trees(az_engine *h, long long new_ec, long long new_bc)
+{
+    Dev &D = h->D;
+    if (new_ec < D.EC) new_ec = D.EC;
+    if (new_bc < D.BC) new_bc = D.BC;
+    if (new_ec > 0x7fffffffLL || new_bc > 0x7fffffffLL) return set_err(h, AZ_ERR_ARG, "tree caps too large");
+    if (new_ec == D.EC && new_bc == D.BC) return AZ_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t T = 2 * (size_t)D.G, rs = D.f64 ? 8 : 4;
+    struct Arr { void **p; size_t elem; bool edge; };
+    Arr arrs[] = {
+        {(void **)&D.eN, 4, true}, {&D.eW, rs, true}, {&D.eP, rs, true}, {(void **)&D.eChild, 4, true}, {(void **)&D.eAct, 2, true},
+        {(void **)&D.bStart, 4, false}, {(void **)&D.bCount, 4, false}, {(void **)&D.bOwner, 4, false},
+        {(void **)&D.bParent, 4, false}, {(void **)&D.bMap, 4, false}, {(void **)&D.bShift, 4, false},
+    };
+    for (Arr &a : arrs) {
+        const size_t oc = a.edge ? (size_t)D.EC : (size_t)D.BC, nc = a.edge ? (size_t)new_ec : (size_t)new_bc;
+        if (oc == nc) continue;
+        void *np_ = nullptr;
+        if (hipMalloc(&np_, T * nc * a.elem) != hipSuccess)
+            return set_err(h, AZ_ERR_HIP, "device allocation failed while enlarging the tree arenas");
+        HIPCHK(hipMemcpy2D(np_, nc * a.elem, *a.p, oc * a.elem, oc * a.elem, T, hipMemcpyDeviceToDevice));
+        for (void *&q : h->allocs)
+            if (q == *a.p) { q = np_; break; }
+        hipFree(*a.p);
+        *a.p = np_;
+    }
+    D.EC = (int)new_ec; D.BC = (int)new_bc;
+    return AZ_OK;
+}
+
+static void launch_tail(az_engine *h);
+static int check_slot_errors(az_engine *h);
+
+// tree_full_policy 2: slots stopped by a full arena get arenas twice the size and their pending playout is completed
+// (their leaf, path and - for the tower - the same planes are still in place).  selfplay: also play due moves.
+static int check_and_grow(az_engine *h, bool selfplay)
+{
+    int rc = check_slot_errors(h);
+    for (int tries = 0; rc == AZ_ERR_TREE_FULL && h->cfg.tree_full_policy == 2 && tries < 8; tries++) {
+        if ((rc = grow_trees(h, 2LL * h->D.EC, 2LL * h->D.BC))) return rc;
+        h->error.clear();
+        hipLaunchKernelGGL(k_clear_tree_full, dim3((h->D.G + 255) / 256), dim3(256), 0, h->stream, h->D);
+        if (selfplay) launch_tail(h);
+        else if (h->D.f64) hipLaunchKernelGGL(k_finish<double>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, -1);
+        else hipLaunchKernelGGL(k_finish<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, -1);
+        rc = check_slot_errors(h);
+    }
+    return rc;
+}
+
+extern "C" int az_search_grow_trees(az_engine *h, int32_t edge_cap, int32_t block_cap)
+{
+    if (!h || edge_cap < 0 || block_cap < 0) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    return grow_trees(h, edge_cap ? edge_cap : 2LL * h->D.EC, block_cap ? block_cap : 2LL * h->D.BC);
+}
+
 extern "C" const char *az_last_error(az_engine *h) { return h ? h->error.c_str() : g_create_error.c_str(); }
 
 extern "C" void az_engine_destroy(az_engine *h)
@@ -150,6 +210,7 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     }
     if (cfg->game == AZ_REVERSI && (H != W || (H & 1))) { g_create_error = "reversi needs an even square board"; return nullptr; }
     if (!(cfg->d_epsilon >= 0.0 && cfg->d_epsilon <= 1.0)) { g_create_error = "d_epsilon must lie in [0, 1]"; return nullptr; }
+    if (cfg->tree_full_policy < 0 || cfg->tree_full_policy > 2) { g_create_error = "tree_full_policy must be 0, 1 or 2"; return nullptr; }
     if (!cfg->rng_replay && !(cfg->d_alpha > 0.0)) { g_create_error = "d_alpha must be positive (random.gammavariate raises otherwise)"; return nullptr; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_error = "no HIP device"; return nullptr; }
@@ -192,7 +253,7 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     D.MAXD = cfg->max_depth > 0 ? cfg->max_depth : 1024;
     D.rng_replay = cfg->rng_replay; D.seed = cfg->seed;
     D.record = cfg->record_trajectories;
-    D.full_policy = cfg->tree_full_policy ? 1 : 0;
+    D.full_policy = cfg->tree_full_policy;
     D.K = cfg->leaves_per_round > 1 ? cfg->leaves_per_round : 1;
     D.vloss = cfg->virtual_loss;
     D.traj_plies = cfg->record_trajectories ? cfg->max_turn + 2 : 1;
@@ -606,7 +667,7 @@ static int step_finish(az_engine *h, const void *priors, const void *values, int
     else hipLaunchKernelGGL(k_finish<float>, dim3(h->D.G), dim3(64), 0, h->stream, h->D, -1);
     HIPCHK(hipGetLastError());
     h->steps++;
-    return check_slot_errors(h);
+    return check_and_grow(h, false);
 }
 
 static int root_stats(az_engine *h, int32_t slot, int32_t side, int32_t *actions, int32_t *visits, void *total_value, void *prior,
@@ -776,7 +837,7 @@ extern "C" int az_selfplay_run(az_engine *h, int32_t n_rounds)
     }
     while (h->ev_pending > 0) { int rc = drain_round(h); if (rc) return rc; }
     HIPCHK(hipGetLastError());
-    return check_slot_errors(h);
+    return check_and_grow(h, true);
 }
 
 // n_rounds of select -> tower -> finish for the searches begun with az_search_begin, queued on the stream with one
@@ -797,7 +858,7 @@ extern "C" int az_search_run(az_engine *h, int32_t n_rounds)
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
-    return check_slot_errors(h);
+    return check_and_grow(h, false);
 }
 
 extern "C" int az_selfplay_select(az_engine *h, int32_t *n_leaves)
@@ -825,7 +886,7 @@ static int selfplay_finish(az_engine *h, const void *priors, const void *values,
     launch_tail(h);
     HIPCHK(hipGetLastError());
     h->steps++;
-    return check_slot_errors(h);
+    return check_and_grow(h, true);
 }
 
 extern "C" int az_selfplay_status(az_engine *h, int32_t *plies, int32_t *done)

@@ -152,9 +152,11 @@ __device__ __forceinline__ void select_one(const Dev &D, const int sub, WLds &L)
 #endif
     const Geo G = D.geo;
     int phase = D.phase[g];
+    // a slot stopped by an error keeps its pending leaf untouched: once the cause is removed (a full tree arena that the
+    // host has enlarged) the finish step completes that playout
+    if (D.err[g] != 0) return;
     if (lane == 0) D.leaf_valid[li] = 0;
     if (phase != PH_NEED_START && phase != PH_IN_SEARCH) return;
-    if (D.err[g] != 0) return;
     // sub-rounds after the first only add playouts to a search that is under way and has budget left
     if (sub > 0 && (phase != PH_IN_SEARCH || D.issued[g] >= D.max_playout)) return;
     const int side = D.side[g];
@@ -318,8 +320,9 @@ __global__ __launch_bounds__(64) void k_select_all(Dev D)
 // finish: expand or terminal value, then backup (mcts.py:217-232, 196-202, 283)
 // ---------------------------------------------------------------------------
 
+// returns 1 when the leaf has been dealt with, 0 when it is left pending (nothing to do, or an error stopped the slot)
 template <typename R>
-__device__ __forceinline__ void finish_one(const Dev &D, const int sub)
+__device__ __forceinline__ int finish_one(const Dev &D, const int sub)
 {
     R *const eW = static_cast<R *>(D.eW);
     R *const eP = static_cast<R *>(D.eP);
@@ -328,7 +331,7 @@ __device__ __forceinline__ void finish_one(const Dev &D, const int sub)
     const int li = sub * D.G + g;
     const int lane = lane_id();
     const Geo G = D.geo;
-    if (!D.leaf_valid[li] || D.err[g] != 0) return;
+    if (!D.leaf_valid[li] || D.err[g] != 0) return 0;
     const int side = D.side[g];
     const int t = 2 * g + side;
     const size_t tb = (size_t)t * D.EC, bb = (size_t)t * D.BC;
@@ -365,7 +368,7 @@ __device__ __forceinline__ void finish_one(const Dev &D, const int sub)
         // a full arena is an error, or (tree_full_policy 1, never at a root) the node simply stays a leaf for this
         // playout: its value is backed up as usual and the event is counted
         const int full = (bi >= D.BC || start + n > D.EC);
-        if (full && (D.full_policy == 0 || root_expand)) { if (lane == 0) D.err[g] = -4; return; }
+        if (full && (D.full_policy != 1 || root_expand)) { if (lane == 0) D.err[g] = -4; return 0; }
         int off = 0;
         for (int i0 = 0; i0 < G.O && !full; i0 += AZ_WAVE) {
             int i = i0 + lane;
@@ -412,7 +415,7 @@ __device__ __forceinline__ void finish_one(const Dev &D, const int sub)
             D.pdone[g] = 0; D.issued[g] = 0;
             D.phase[g] = D.max_playout == 0 ? PH_SEARCH_DONE : PH_IN_SEARCH;
         }
-        return;
+        return 1;
     }
     // ancestors: node.update(-current_player * simres_value)
     int plen = D.path_len[li];
@@ -426,6 +429,7 @@ __device__ __forceinline__ void finish_one(const Dev &D, const int sub)
         D.pdone[g] = pd;
         if (pd >= D.max_playout) D.phase[g] = PH_SEARCH_DONE;
     }
+    return 1;
 }
 
 // sub as in k_select: one sub-round, or (sub < 0) all of them in order within one launch
@@ -434,7 +438,11 @@ __global__ __launch_bounds__(64) void k_finish(Dev D, int sub)
 {
     const int first = sub >= 0 ? sub : 0, last = sub >= 0 ? sub + 1 : D.K;
     for (int j = first; j < last; j++) {
-        finish_one<R>(D, j);
+        const int done = finish_one<R>(D, j);
+        WSYNC();
+        // a leaf is consumed exactly once: running the finish step again (after a tree arena was enlarged) only
+        // completes what an error left pending
+        if (done && lane_id() == 0) D.leaf_valid[j * D.G + blockIdx.x] = 0;
         WSYNC();
     }
 }
@@ -818,6 +826,13 @@ __global__ __launch_bounds__(64) void k_choose(Dev D, int g, int side, double u,
     int n = 0;
     int mv = dev_choose(D, L, 2 * g + side, u, &n);
     if (lane_id() == 0) out[0] = mv;
+}
+
+// after the tree arenas were enlarged: slots stopped by a full arena may go on
+__global__ void k_clear_tree_full(Dev D)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < D.G && D.err[g] == -4) D.err[g] = 0;
 }
 
 // A leaf row needs the evaluator unless it is a terminal state below the root: that one takes its value from the rules

@@ -188,6 +188,10 @@ class Engine:
         s, m = _i32(slots), _i32(moves)
         self._ck(self._L.az_search_advance(self._h, s.ctypes.data, s.size, m.ctypes.data))
 
+    def grow_trees(self, edge_cap=0, block_cap=0):
+        """Enlarge every tree's arena (0 = double); contents are kept."""
+        self._ck(self._L.az_search_grow_trees(self._h, int(edge_cap), int(block_cap)))
+
     def tree_size(self, slot, side):
         e, b = C.c_int32(0), C.c_int32(0)
         self._ck(self._L.az_search_tree_size(self._h, slot, side, C.byref(e), C.byref(b)))

@@ -80,7 +80,11 @@ class NNEvaluator:
     def load(self, filename):
         self.rwlock.w_acquire()
         try:
-            self.net.load_state_dict(torch.load(filename, weights_only=True))
+            # either a bare state dict (save() below) or the optimizer side's checkpoint (network/train.py Network.save:
+            # {'model', 'opt', 'global_step'} in '<prefix>-<step>'), which is how weights reach the evaluators in the
+            # reference: net.save('.../ckpt') then nn_eval.load('.../ckpt-<step>') (train/parallel/evaluator.py:109)
+            ck = torch.load(filename, weights_only=True, map_location="cpu")
+            self.net.load_state_dict(ck["model"] if "model" in ck else ck)
             self._refold()
         finally:
             self.rwlock.w_release()

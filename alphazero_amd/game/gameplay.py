@@ -127,21 +127,42 @@ class BatchedSelfplay:
     `eng.counters()["expansions_skipped"]` tells how often that happened (0 = the run is exact).
 
     Finished games are turned into get_history() tuples on a second engine (its own HIP stream) by a
-    background thread, so the self-play engine keeps running rounds meanwhile."""
+    background thread, so the self-play engine keeps running rounds meanwhile.
+
+    New weights (nn_eval.load / set_weights bump nn_eval.version; selfplay.py:110-122) are picked up between polls.
+    update="immediate" (default): the games in flight continue with the new network from the next round on.
+    update="drain": as in the reference, where every running game holds the evaluator's read lock and the reload waits
+    for all of them - finished slots are not re-armed until every game in flight has ended, then the weights are
+    loaded and all slots start again, so no game ever sees two networks.
+
+    rng_streams: optional list of (transform ids, gamma draws, uniforms), one per slot - the engine then replays these
+    draws instead of using its own generator (parity tests)."""
 
     REPLAY_SLOTS = 64
 
-    def __init__(self, nn_eval, game_config, ext_config, n_games, seed=0, device=0):
+    def __init__(self, nn_eval, game_config, ext_config, n_games, seed=0, device=0, update="immediate", rng_streams=None):
+        if update not in ("immediate", "drain"):
+            raise ValueError("update must be 'immediate' or 'drain'")
         kw = game_config_to_engine_kwargs(game_config)
         self.eng = Engine(n_slots=n_games, max_playout=ext_config['player']['max_playout'],
                           dirichlet_before=ext_config['dirichlet_before'], max_turn=ext_config['max_turn'],
                           record_trajectories=True, seed=seed, num_blocks=nn_eval.num_blocks, channels=nn_eval.channels,
-                          tower_dtype=nn_eval.dtype, device=device, tree_full_policy=1, **kw)
+                          tower_dtype=nn_eval.dtype, device=device, tree_full_policy=1, rng_replay=rng_streams is not None, **kw)
+        if rng_streams is not None:
+            if len(rng_streams) != n_games:
+                raise ValueError("one (tids, etas, unis) triple per slot")
+            for s, st in enumerate(rng_streams):
+                self.eng.rng_inject(s, *st)
         self._nn_eval = nn_eval
         self._version = None
         self._replay = Engine(n_slots=self.REPLAY_SLOTS, device=device, **kw)
         self.n_games = n_games
         self._started = False
+        self._update = update
+        self._draining = False
+        self._empty = np.zeros(n_games, bool)   # slots popped without a restart while draining
+        self._surplus = []                      # (slot, history) of games that finished beyond an earlier run()'s request
+        self.last_slots = []                    # slot of every game the last run() returned
 
     def _sync_weights(self):
         if self._version != self._nn_eval.version:
@@ -154,26 +175,47 @@ class BatchedSelfplay:
             out += history_arrays_batch(self._replay, popped[i:i + self.REPLAY_SLOTS])
         return out
 
+    def _weights_between_polls(self):
+        if self._version == self._nn_eval.version:
+            return
+        if self._update == "immediate" or self._version is None:
+            self._sync_weights()
+        else:
+            self._draining = True
+
     def run(self, num_games, rounds_per_poll=64):
-        """Play until `num_games` games have finished; returns their get_history() tuples in finishing order."""
+        """Play until `num_games` games have finished; returns their get_history() tuples in finishing order.  Games
+        that finish in the same poll beyond the request are kept and returned first by the next call."""
         from concurrent.futures import ThreadPoolExecutor
-        self._sync_weights()
+        self._weights_between_polls()
         if not self._started:
             self.eng.selfplay_start()
             self._started = True
-        n_popped, pending = 0, []
+        slots = [s for s, _ in self._surplus]
+        ready = [h for _, h in self._surplus]
+        pending = []
         with ThreadPoolExecutor(max_workers=1) as pool:   # one worker: conversions stay in finishing order
-            while n_popped < num_games:
+            while len(slots) < num_games:
                 self.eng.selfplay_run(rounds_per_poll)    # the C call releases the GIL: the worker converts meanwhile
                 plies, done = self.eng.selfplay_status()
-                fin = np.flatnonzero(done)
+                fin = np.flatnonzero((done != 0) & ~self._empty)
                 popped = [(tr["moves"], tr["visits"], tr["winner"])
-                          for tr in self.eng.trajectory_pop_many(fin, plies[fin], restart=True)]
+                          for tr in self.eng.trajectory_pop_many(fin, plies[fin], restart=not self._draining)]
                 if popped:
-                    n_popped += len(popped)
+                    slots += [int(s) for s in fin]
                     pending.append(pool.submit(self._convert, popped))
-                self._sync_weights()
-            out = [h for f in pending for h in f.result()]
+                if self._draining:
+                    self._empty[fin] = True
+                    if self._empty.all():                 # every game in flight has ended: swap the network, start over
+                        self._sync_weights()
+                        self.eng.selfplay_start()
+                        self._empty[:] = False
+                        self._draining = False
+                else:
+                    self._weights_between_polls()
+            out = ready + [h for f in pending for h in f.result()]
+        self._surplus = list(zip(slots[num_games:], out[num_games:]))
+        self.last_slots = slots[:num_games]
         return out[:num_games]
 
 

@@ -65,7 +65,11 @@ class Network:
         self.opt = torch.optim.SGD(self.net.parameters(), lr=piecewise_lr(0, cfg["learning_rate"]),
                                    momentum=float(cfg["momentum"]), dampening=0.0, nesterov=False)
         if load_pretrained:
-            self.load(os.path.join(cfg["save_dir"], "latest.pt"))
+            # network/main.py:92-95 restores tf.train.latest_checkpoint(save_dir): the newest '<prefix>-<step>' of save()
+            path = latest_checkpoint(cfg["save_dir"])
+            if path is None:
+                raise FileNotFoundError("no '<prefix>-<step>' checkpoint in %r" % cfg["save_dir"])
+            self.load(path)
 
     def _t(self, a):
         return torch.as_tensor(np.asarray(a), dtype=torch.float32, device=self.device)
@@ -113,7 +117,24 @@ class Network:
         return path
 
     def load(self, filename):
+        """A file of save(), or a bare state dict as NNEvaluator.save writes it (weights only: step and optimizer
+        state are then left as they are)."""
         ck = torch.load(filename, weights_only=True, map_location=self.device)
+        if "model" not in ck:
+            self.net.load_state_dict(ck)
+            return
         self.net.load_state_dict(ck["model"])
         self.opt.load_state_dict(ck["opt"])
         self.global_step = int(ck["global_step"])
+
+
+def latest_checkpoint(save_dir):
+    """Path of the '<prefix>-<step>' file with the largest step in save_dir (what Network.save writes), or None."""
+    import re
+    best, best_step = None, -1
+    if os.path.isdir(save_dir):
+        for name in os.listdir(save_dir):
+            m = re.fullmatch(r".*-(\d+)", name)
+            if m and int(m.group(1)) > best_step and os.path.isfile(os.path.join(save_dir, name)):
+                best, best_step = os.path.join(save_dir, name), int(m.group(1))
+    return best

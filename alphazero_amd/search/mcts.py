@@ -83,8 +83,10 @@ class MCTSearch(object):
         if leaves_per_round > 1 and self._tower is None:
             raise ValueError("leaves_per_round > 1 needs a device evaluator (NNEvaluator)")
         # replayed draws follow the reference's sequential order, which several leaves in flight do not have
+        # the reference's tree has no size limit and a re-rooted tree keeps the chosen child's subtree (a sharply peaked
+        # policy keeps most of it, ply after ply): the arenas double whenever one fills up (tree_full_policy 2)
         self._eng_kw = dict(n_slots=1, max_playout=max_playout, rng_replay=leaves_per_round <= 1,
-                            leaves_per_round=leaves_per_round, **kw)
+                            leaves_per_round=leaves_per_round, tree_full_policy=2, **kw)
         self._multi = leaves_per_round > 1
         self._K = max(1, int(leaves_per_round))
         self._eng = Engine(**self._eng_kw, **tower_kw)

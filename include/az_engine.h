@@ -75,7 +75,9 @@ typedef struct az_config {
     double virtual_loss;       /* K > 1: subtracted from W of every edge on a path in flight, given back when its value arrives */
     int32_t tree_full_policy;  /* 0: a full tree arena stops the run with AZ_ERR_TREE_FULL (the reference has no limit, so
                                   nothing else is exact); 1: the node stays a leaf for that playout, its value is still
-                                  backed up, and az_counters.expansions_skipped counts the event (production runs) */
+                                  backed up, and az_counters.expansions_skipped counts the event (production runs);
+                                  2: the arenas of all trees are doubled and the stopped playout is completed when the
+                                  call that ran the round returns - exact like 0, without the limit (single games) */
     int32_t search_f64;        /* 0: N/W/P arithmetic in float32 (a float32 evaluator: the network, nn_eval_parallel.py:75-92);
                                   1: in float64 (an evaluator returning Python floats / float64: evaluator/dummy_eval.py:26-28).
                                   With 1 the tower cannot feed the search; use the *_f64 entry points */
@@ -177,6 +179,9 @@ int az_search_choose(az_engine *h, int32_t slot, int32_t side, double u, int32_t
 /* MCTSearch.update_with_move for one tree / Player.ack for both trees of a slot */
 int az_search_advance_tree(az_engine *h, int32_t slot, int32_t side, int32_t move);
 int az_search_advance(az_engine *h, const int32_t *slots, int32_t n, const int32_t *moves);
+/* Enlarge the arenas of every tree to edge_cap edges / block_cap expanded nodes (0 = twice the present size; never
+ * shrinks); the trees keep their contents.  What tree_full_policy 2 does by itself. */
+int az_search_grow_trees(az_engine *h, int32_t edge_cap, int32_t block_cap);
 /* nodes (edges) and expanded nodes currently held by a tree */
 int az_search_tree_size(az_engine *h, int32_t slot, int32_t side, int32_t *edges, int32_t *blocks);
 

@@ -282,3 +282,142 @@ def test_batched_history_replay_matches_single_game_replay():
         s1, p1, r1 = history_arrays(e1, m, v, w)
         assert np.array_equal(s, s1) and np.array_equal(p, p1) and np.array_equal(r, r1)
     eb.close(); e1.close()
+
+
+class _PeakedEvaluator:
+    """0.99 on the first empty point: the chosen child keeps nearly all visits, so a re-rooted tree keeps nearly
+    everything and grows by about max_playout nodes per ply."""
+
+    def __init__(self, cfg):
+        import alphazero_amd.processing.state_converter as sc
+        self.O = cfg["flat_move_output"]
+        self.t2a = sc.TensorActionConverter(cfg)
+
+    def eval(self, state):
+        b = np.asarray(state.board).ravel()
+        pri = np.full(self.O, np.float32(0.01) / np.float32(self.O - 1), np.float32)
+        pri[int(np.argmax(b == 0))] = np.float32(0.99)
+        return self.t2a.tensor_to_action(pri), np.float32(0.1)
+
+
+def test_search_tree_outgrows_the_default_arena_without_error():
+    """The reference's tree has no size limit.  A sharply peaked policy played for 35 plies with tree reuse fills the
+    drop-in MCTSearch's default arenas several times over; they grow and the game goes on."""
+    import alphazero_amd.env.go as go
+    from alphazero_amd.player.mcts_player import Player
+    H, P = 9, 60
+    cfg = _cfg("go", H, H, H * H + 1, 0)       # no transforms: both players' trees peak on the same points
+    ev = _PeakedEvaluator(cfg)
+    p1, p2 = Player(ev, cfg, {"max_playout": P}), Player(ev, cfg, {"max_playout": P})
+    eng = p1.mcts._eng
+    cap0 = eng.counters()["tree_block_cap"]
+    st = go.GameState(size=H)
+    cur = p1
+    for ply in range(35):
+        move, probs = cur.think(st, False)
+        assert abs(sum(p for _, p in probs) - 1.0) < 1e-9
+        st.do_move(move)
+        p1.ack(move); p2.ack(move)
+        cur = p2 if cur is p1 else p1
+    c = eng.counters()
+    assert c["tree_block_cap"] > cap0 and c["peak_tree_blocks"] > cap0 and c["expansions_skipped"] == 0
+
+
+def test_optimizer_checkpoint_loads_into_the_evaluator(tmp_path):
+    """Weights reach the evaluators through a file: the optimizer's Network.save('<dir>/ckpt') writes 'ckpt-<step>' and
+    the evaluator loads that path (train/parallel/optimization.py:99-101, evaluator.py:109).  Both sides must then give
+    the same response."""
+    import alphazero_amd.env.mnk as mnk
+    from alphazero_amd.evaluator.nn_eval import NNEvaluator
+    from alphazero_amd.network.train import Network
+    cfg = _cfg("mnk", 3, 3, 9, 0, 3)
+    mnk.game_config.update(board_height=3, board_width=3, k=3)
+    train = {"num_blocks": 1, "batch_decay": 0.9, "learning_rate": {0: 1e-2, 20: 1e-2, 40: 1e-3, 60: 1e-4, 70: 1e-4}, "momentum": 0.9,
+             "l2": 1e-4, "MSE_scaling": 1.0, "save_dir": str(tmp_path)}
+    nw = Network(cfg, train_config=train, device="cpu", channels=128)
+    rng = np.random.RandomState(0)
+    data = ((rng.rand(6, 17, 3, 3) < 0.3).astype(np.float64), np.eye(9)[rng.randint(0, 9, 6)], rng.choice([-1.0, 1.0], 6))
+    for _ in range(3):
+        nw.update(data)
+    path = nw.save(str(tmp_path / "ckpt"))
+    ev = NNEvaluator(cfg, num_blocks=1, channels=128, dtype="fp32", max_batch_size=8, seed=9)
+    before = ev.eval_batch(data[0].astype(np.int8))[0]
+    v0 = ev.version
+    ev.load(path)
+    assert ev.version == v0 + 1
+    p, v = ev.eval_batch(data[0].astype(np.int8))
+    rp, rv = nw.response(data)
+    assert np.abs(p - rp).max() < 1e-5 and np.abs(v - rv).max() < 1e-5 and np.abs(p - before).max() > 1e-4
+    # and back: the evaluator's own file loads into the training side (weights only)
+    ev.save(str(tmp_path / "eval.pt"))
+    nw2 = Network(cfg, train_config=train, device="cpu", channels=128)
+    nw2.load(str(tmp_path / "eval.pt"))
+    assert np.array_equal(nw2.response(data)[0], rp)
+    mnk.game_config.update(board_height=6, board_width=5, k=4)
+
+
+def test_batched_selfplay_reproduces_the_oracle_games():
+    """BatchedSelfplay.run (the role of Selfplay.run + selfplay_wrapper, train/parallel/selfplay.py:71-108) with replayed
+    draws against the oracle's oz_play_game fed by the same network: identical get_history() tuples for 8 games.
+    The oracle evaluates its leaves one by one on the same HIP tower (float32; every board is computed independently
+    of its batch neighbours, so single-leaf and batched evaluations agree bit for bit)."""
+    import alphazero_amd.env.reversi  # noqa: F401  (env_path of the config)
+    from alphazero_amd.evaluator.nn_eval import NNEvaluator
+    from alphazero_amd.game.gameplay import BatchedSelfplay, outcome_labels
+    from oracle import oracle as oz
+    H, P, db, mt, G = 6, 16, 5, 400, 8
+    cfg = _cfg("reversi", H, H, H * H + 1, 8)
+    O = cfg["flat_move_output"]
+    ev = NNEvaluator(cfg, num_blocks=1, channels=128, dtype="fp32", max_batch_size=4, seed=4)
+    rng = np.random.RandomState(5)
+    n_plies = 2 * (H * H + 8)          # room for a second game in every slot (slots are re-armed when popped)
+    streams = [(rng.randint(0, 8, size=n_plies * (P + 1)).astype(np.int32), rng.gamma(0.03, 1.0, size=n_plies * O), rng.rand(n_plies))
+               for _ in range(G)]
+    sp = BatchedSelfplay(ev, cfg, {"player": {"max_playout": P}, "dirichlet_before": db, "max_turn": mt}, n_games=G,
+                         rng_streams=streams)
+    hist = sp.run(G, rounds_per_poll=100000)      # one poll: every slot finishes its first game before any is popped
+    assert sorted(sp.last_slots) == list(range(G)) and sp.eng.counters()["expansions_skipped"] == 0
+
+    def one_leaf(planes, O_):
+        p, v = ev.eval_batch(np.ascontiguousarray(planes)[None])
+        return p[0], v[0]
+    cb = oz.make_eval(one_leaf)
+    for slot, (state_np, probs_np, result_np) in zip(sp.last_slots, hist):
+        ref = oz.play_game("reversi", H, H, 0, 8, P, db, mt, cb, oz.Rng(*streams[slot]))
+        T = len(ref["moves"])
+        st = oz.State("reversi", H, H)
+        ref_state = np.zeros((T, 17, H, H))
+        for i in range(T):
+            ref_state[i] = st.features(0)
+            st.do_move(int(ref["moves"][i]))
+        v = ref["visits"].astype(np.float64)
+        assert state_np.shape == ref_state.shape and np.array_equal(state_np, ref_state), slot
+        assert np.array_equal(probs_np, v / v.sum(axis=1, keepdims=True)), slot
+        assert np.array_equal(result_np, outcome_labels(T, ref["winner"])), slot
+
+
+def test_batched_selfplay_keeps_surplus_games_and_drains_for_new_weights():
+    """Games that finish beyond a run()'s request are handed out by the next call, not dropped; update='drain' lets
+    every game in flight end under the old network before the new one is loaded (the reference's reload waits for the
+    read locks that running games hold, selfplay.py:76,87,117-122)."""
+    import alphazero_amd.env.mnk as mnk
+    from alphazero_amd.evaluator.nn_eval import NNEvaluator
+    from alphazero_amd.game.gameplay import BatchedSelfplay
+    from alphazero_amd.network.model import random_net
+    cfg = _cfg("mnk", 3, 3, 9, 0, 3)
+    mnk.game_config.update(board_height=3, board_width=3, k=3)
+    ev = NNEvaluator(cfg, num_blocks=1, channels=128, dtype="fp32", max_batch_size=4, seed=5)
+    ext = {"player": {"max_playout": 10}, "dirichlet_before": 30, "max_turn": 400}
+    sp = BatchedSelfplay(ev, cfg, ext, n_games=16, seed=3, update="drain")
+    first = sp.run(3, rounds_per_poll=11 * 9 + 5)          # one poll finishes all 16 games; 3 are asked for
+    assert len(first) == 3 and len(sp._surplus) == 13
+    finished_before = sp.eng.counters()["games_finished"]
+    second = sp.run(13)                                     # served from the kept games: nothing new is played
+    assert len(second) == 13 and sp.eng.counters()["games_finished"] == finished_before and not sp._surplus
+    v_old = sp._version
+    ev.set_weights(random_net(3, 3, 9, 1, 128, seed=77).state_dict())
+    third = sp.run(20, rounds_per_poll=7)                   # short polls: slots end at different times and wait
+    assert len(third) == 20 and sp._version == ev.version != v_old and not sp._draining
+    for s, p, r in first + second + third:
+        assert 5 <= s.shape[0] <= 9 and np.allclose(p.sum(axis=1), 1.0)
+    mnk.game_config.update(board_height=6, board_width=5, k=4)

@@ -197,6 +197,50 @@ def test_tree_arena_overflow_policy_skip_keeps_searching():
     eng.close()
 
 
+def _peaked_eval(planes, O):
+    """0.99 on the first empty point of the (transformed) board, the rest spread evenly; value 0.1.  With such priors
+    almost every visit goes to one child, whose subtree survives the re-root: the trees keep growing ply after ply."""
+    single = planes.ndim == 3
+    if single:
+        planes = planes[None]
+    B = planes.shape[0]
+    occ = (planes[:, 14] + planes[:, 15]).reshape(B, -1)
+    first = np.argmax(occ == 0, axis=1)
+    pri = np.full((B, O), np.float32(0.01) / np.float32(O - 1), np.float32)
+    pri[np.arange(B), first] = np.float32(0.99)
+    val = np.full(B, np.float32(0.1), np.float32)
+    return (pri[0], val[0]) if single else (pri, val)
+
+
+def test_tree_arenas_grow_and_stay_exact():
+    """tree_full_policy 2: arenas far too small for the retained subtrees double as often as needed; the stopped
+    playout is completed, so whole games still equal the oracle's (whose trees have no limit), visit for visit."""
+    from alphazero_amd.engine import Engine
+    game, H, P, db, mt, G = "go", 7, 40, 6, 30, 3
+    rng = np.random.RandomState(21)
+    eng = Engine(game, H, H, n_slots=G, max_playout=P, transform_types=8, dirichlet_before=db, max_turn=mt, rng_replay=True,
+                 record_trajectories=True, tree_edge_cap=150, tree_block_cap=6, tree_full_policy=2)
+    O = eng.O
+    streams = []
+    for s in range(G):
+        st = (rng.randint(0, 8, size=(mt + 2) * (P + 1)).astype(np.int32), rng.gamma(0.03, 1.0, size=(mt + 2) * O), rng.rand(mt + 2))
+        streams.append(st)
+        eng.rng_inject(s, *st)
+    eng.selfplay_start()
+    while eng.selfplay_select() > 0:
+        planes, _ = eng.leaf_batch()
+        eng.selfplay_finish(*_peaked_eval(planes, O))
+    c = eng.counters()
+    assert c["tree_edge_cap"] > 150 and c["tree_block_cap"] > 6 and c["expansions_skipped"] == 0
+    assert c["peak_tree_blocks"] > 6
+    ev = oz.make_eval(_peaked_eval)
+    for s in range(G):
+        ref = oz.play_game(game, H, H, 0, 8, P, db, mt, ev, oz.Rng(*streams[s]))
+        tr = eng.trajectory_pop(s)
+        assert np.array_equal(tr["moves"], ref["moves"]) and np.array_equal(tr["visits"], ref["visits"]) and tr["winner"] == ref["winner"], s
+    eng.close()
+
+
 def test_reroot_keeps_subtree_and_compacts():
     """update_with_move: the kept child's statistics survive, the arena shrinks, a move that is
     not a child gives a fresh root (search/mcts.py:336-346)."""

@@ -102,3 +102,25 @@ def test_response_evaluate_save_load(tmp_path):
     p2, v2 = nw2.response((state,))
     p1, v1 = nw.response((state,))
     assert np.array_equal(p1, p2) and np.array_equal(v1, v2) and nw2.get_global_step() == 1
+
+
+def test_load_pretrained_takes_the_newest_step(tmp_path):
+    """load_pretrained restores the latest '<prefix>-<step>' of save_dir, as tf.train.latest_checkpoint does for the
+    reference (network/main.py:92-95)."""
+    from alphazero_amd.network.train import latest_checkpoint
+    cfg = dict(TRAIN, save_dir=str(tmp_path))
+    assert latest_checkpoint(str(tmp_path)) is None
+    nw = Network(CFG, train_config=cfg, device="cpu", channels=128)
+    rng = np.random.RandomState(3)
+    data = ((rng.rand(4, 17, 3, 3) < 0.3).astype(np.float64), np.eye(9)[rng.randint(0, 9, 4)], rng.choice([-1.0, 1.0], 4))
+    for _ in range(3):
+        nw.update(data)
+        nw.save(str(tmp_path / "ckpt"))          # ckpt-1, ckpt-2, ckpt-3
+    (tmp_path / "notes.txt").write_text("x")
+    assert latest_checkpoint(str(tmp_path)).endswith("ckpt-3")
+    nw2 = Network(CFG, train_config=cfg, device="cpu", channels=128, load_pretrained=True)
+    assert nw2.get_global_step() == 3
+    assert np.array_equal(nw2.response(data)[0], nw.response(data)[0])
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        Network(CFG, train_config=dict(TRAIN, save_dir=str(tmp_path / "none")), device="cpu", channels=128, load_pretrained=True)
