@@ -90,6 +90,7 @@ SIGNATURES = {
     "az_selfplay_status": (_I, [_P, _P, _P]),
     "az_trajectory_pop": (_I, [_P, _I, _P, _P, _P, _I]),
     "az_trajectory_pop_many": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _I]),
+    "az_trajectory_pop_many_dev": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _I]),
     "az_trajectory_pop_many_static": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _I]),
     "az_trajectory_max_plies": (_I, [_P]),
     "az_rng_inject": (_I, [_P, _I, _P, C.c_int64, _P, C.c_int64, _P, C.c_int64]),

@@ -983,6 +983,43 @@ extern "C" int az_trajectory_pop_many(az_engine *h, const int32_t *slots, int32_
     return AZ_OK;
 }
 
+extern "C" int az_trajectory_pop_many_dev(az_engine *h, const int32_t *slots, int32_t n, const int32_t *row_start, int32_t total_rows,
+                                          int16_t *moves_dev, int32_t *visits_dev, int32_t *winners, int32_t restart)
+{
+    int rc = check_slots(h, slots, n);
+    if (rc) return rc;
+    if (n == 0) return AZ_OK;
+    if (!row_start || !winners || total_rows < 0 || (total_rows > 0 && (!moves_dev || !visits_dev))) return set_err(h, AZ_ERR_ARG, "null argument");
+    const Dev &D = h->D;
+    if (!D.record) return set_err(h, AZ_ERR_STATE, "the engine was created without record_trajectories");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int G = D.G;
+    std::vector<int32_t> ph(G), ply(G), win(G);
+    HIPCHK(hipMemcpyAsync(ph.data(), D.phase, sizeof(int32_t) * G, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(ply.data(), D.ply, sizeof(int32_t) * G, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(win.data(), D.tr_winner, sizeof(int32_t) * G, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    long long expect = 0;
+    std::vector<char> seen(G, 0);
+    for (int i = 0; i < n; i++) {
+        const int s = slots[i];
+        if (seen[s]) return set_err(h, AZ_ERR_ARG, "duplicate slot");
+        seen[s] = 1;
+        if (ph[s] != PH_GAME_DONE) return set_err(h, AZ_ERR_STATE, "a game in the list is not finished");
+        if (row_start[i] != expect) return set_err(h, AZ_ERR_ARG, "row_start is not the running sum of the games' plies");
+        expect += std::min(ply[s], D.traj_plies);
+    }
+    if (expect != total_rows) return set_err(h, AZ_ERR_ARG, "total_rows does not match the games' plies");
+    if ((rc = up(h, h->st_a, slots, n)) || (rc = up(h, h->st_b, row_start, n))) return rc;
+    hipLaunchKernelGGL(k_traj_gather, dim3(n), dim3(256), 0, h->stream, h->D, (const int32_t *)h->st_a, (const int32_t *)h->st_b, n,
+                       moves_dev, visits_dev);
+    if (restart) hipLaunchKernelGGL(k_reset, dim3(n), dim3(64), 0, h->stream, h->D, (const int32_t *)h->st_a, n, 1);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    for (int i = 0; i < n; i++) winners[i] = win[slots[i]];
+    return AZ_OK;
+}
+
 // phase, ply and winner of the listed slots -> meta[0..n), meta[256..), meta[512..)
 __global__ void k_traj_meta(Dev D, const int32_t *__restrict__ slots, int n, int32_t *__restrict__ meta)
 {

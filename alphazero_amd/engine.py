@@ -251,6 +251,26 @@ class Engine:
         return [dict(moves=moves[a:a + k].copy(), visits=visits[a:a + k].copy(), winner=int(w))
                 for a, k, w in zip(start.tolist(), n_rows.tolist(), win.tolist())]
 
+    def trajectory_pop_many_torch(self, slots, plies, restart=False):
+        """Finished slots' trajectories as device tensors: (moves int16 (rows,), visits int32 (rows, O), plies int64
+        (n,), winners int32 (n,)), the games' rows back to back; nothing crosses PCIe but the per-game scalars."""
+        import torch
+        s = _i32(slots)
+        mp = self._L.az_trajectory_max_plies(self._h)
+        n_rows = np.minimum(_i32(plies), mp).astype(np.int64)
+        start = np.zeros(s.size, np.int32)
+        if s.size:
+            start[1:] = np.cumsum(n_rows)[:-1]
+        total = int(n_rows.sum())
+        dev = torch.device("cuda", self.cfg.device)
+        moves = torch.empty(total, dtype=torch.int16, device=dev)
+        visits = torch.empty((total, self.O), dtype=torch.int32, device=dev)
+        win = np.zeros(s.size, np.int32)
+        torch.cuda.current_stream(dev).synchronize()
+        self._ck(self._L.az_trajectory_pop_many_dev(self._h, s.ctypes.data, s.size, start.ctypes.data, total, moves.data_ptr(),
+                                                    visits.data_ptr(), win.ctypes.data, int(restart)))
+        return moves, visits, n_rows, win
+
     # ---- rng ---------------------------------------------------------------------
     def rng_inject(self, slot, tids=(), etas=(), unis=()):
         t = np.ascontiguousarray(tids, np.int32); e = np.ascontiguousarray(etas, np.float64)

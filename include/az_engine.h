@@ -205,6 +205,11 @@ int az_trajectory_max_plies(az_engine *h);
  * the running sum of the plies az_selfplay_status reported and total_rows their sum (checked). winners[n]. */
 int az_trajectory_pop_many(az_engine *h, const int32_t *slots, int32_t n, const int32_t *row_start, int32_t total_rows,
                            int16_t *moves, int32_t *visits, int32_t *winners, int32_t restart);
+/* The same with the packed rows left in this GPU's memory: moves_dev[total_rows] and visits_dev[total_rows][O] are device
+ * pointers of the caller (e.g. torch tensors), so finished games can be compacted and sent on to the replay buffer's
+ * rank without a pass through host memory; winners[n] is a host array.  Returns after the engine's stream is idle. */
+int az_trajectory_pop_many_dev(az_engine *h, const int32_t *slots, int32_t n, const int32_t *row_start, int32_t total_rows,
+                               int16_t *moves_dev, int32_t *visits_dev, int32_t *winners, int32_t restart);
 /* az_trajectory_pop_many for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc); it has no counterpart in the reference.  Same arguments and results, but the device-side
  * staging of the packed rows is a fixed array inside the library (one per GPU, AZ_STATIC_POP_BYTES, held until the
