@@ -42,58 +42,40 @@ def measured_traffic(games, board, channels):
     return int(d["traffic_bytes_per_launch"] * games / d["boards"]), d["source"] + "; measured at %d boards, scaled to %d" % (d["boards"], games)
 
 
-def cpu_baseline(game, H, k, num_blocks, channels, sims, budget_s=20.0):
-    """The CPU oracle (C port of the reference's rules/search) driving an fp32 PyTorch-CPU restatement of
-    the network, one leaf per evaluation as the reference's per-game search sees it; bounded sample."""
-    import numpy as np
-    import torch
-    from alphazero_amd.network.model import random_net
-    from oracle import oracle as oz
-    from oracle import tower_ref
+def cpu_baseline(game, H, k, num_blocks, channels, sims, budget_s=12.0):
+    """The CPU oracle (C port of the reference's rules/search) driving an fp32 PyTorch-CPU restatement of the network,
+    one leaf per evaluation as the reference's per-game search sees it.  Two shapes, a bounded sample each: P single-thread
+    game processes side by side (how the reference runs self-play: one process per game, num_worker of them), which is
+    `value`, and one process with all P threads in the network.  The reference's own Python numbers for the same shapes,
+    taken in the build container by oracle/ref_cpu_baseline.py, travel as a data fixture and are quoted beside them."""
+    from oracle import port_baseline
 
-    O = H * H + (0 if game == "mnk" else 1)
-    net = random_net(H, H, O, num_blocks, channels, seed=0)
-    sd = net.state_dict()
-    cores = torch.get_num_threads()
-    n_eval = [0]
-
-    def ev(planes, O_):
-        n_eval[0] += 1
-        x = torch.from_numpy(np.ascontiguousarray(planes)).float()[None]
-        p, v = tower_ref.forward(sd, x, num_blocks)
-        return p[0].numpy(), float(v[0])
-
-    cb = oz.make_eval(ev)
-    st = oz.State(game, H, H, k) if game == "mnk" else oz.State(game, H, H)
-    tree = oz.Tree(O, 8)
-    rng = oz.Rng(seed=1)
-    # calibrate with a few playouts, then size the sample to the budget
-    t0 = time.perf_counter()
-    tree.search(st, 4, True, cb, rng)
-    per = (time.perf_counter() - t0) / max(n_eval[0], 1)
-    n = int(max(8, min(sims, budget_s / max(per, 1e-6))))
-    tree = oz.Tree(O, 8)
-    n_eval[0] = 0
-    t0 = time.perf_counter()
-    tree.search(st, n, True, cb, rng)
-    dt = time.perf_counter() - t0
-    sims_per_s = n_eval[0] / dt
+    # the GPU box gives a one-GPU job 16 host cores (os.cpu_count() reports the whole machine)
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    cfgt = (game, H, k, sims, num_blocks, channels, 8)
+    m = port_baseline.measure(cfgt, budget_s, cores)
     ref = None
-    try:  # the reference's own Python search timed in the build container (it cannot run on the GPU box): data fixture
+    try:
         with open(os.path.join(ROOT, "tests", "golden", "cpu_baseline_reference.json")) as f:
             ref = json.load(f)
     except OSError:
         pass
+    name = {tuple(v[:5]): n for n, v in port_baseline.CONFIGS.items()}.get((game, H, k if game == "mnk" else 0, sims, num_blocks))
+    rec = (ref or {}).get("configs", {}).get(name) if name else None
     est = None
-    if ref and "reference_over_port_torch_fp32" in ref:
-        # port timing on this host x (reference / port) ratio measured side by side in the build container
-        est = sims_per_s * ref["reference_over_port_torch_fp32"]
+    if rec:
+        # port timing on this host x (reference / port) ratio measured side by side, same shape, in the build container
+        est = m["processes"]["sims_per_sec"] * rec["torch_fp32"]["reference_over_port_processes"]
     return {
+        "value": m["processes"]["moves_per_sec"], "unit": "moves/s", "sims_per_sec": m["processes"]["sims_per_sec"], "cores": cores,
+        "kind": "port",
+        "sample": "%d single-thread game processes for %.0f s each on %s %dx%d, %d sims/move (%d-block %d-ch fp32 net on CPU, one leaf "
+                  "per evaluation, searches from the opening); moves/s = sims/s / %d" % (cores, budget_s, game, H, H, sims, num_blocks,
+                                                                                       channels, sims + 1),
+        "single_process_all_threads": m["single"],
         "reference_equivalent_sims_per_sec_estimate": est,
-        "reference_python_in_build_container": ref,
-        "value": sims_per_s / (sims + 1), "unit": "moves/s", "sims_per_sec": sims_per_s, "cores": cores, "kind": "port",
-        "sample": "first %d simulations of one %s %dx%d game's first search (%d-block %d-ch fp32 net on CPU, "
-                  "one leaf per evaluation); moves/s = sims/s / %d" % (n_eval[0], game, H, H, num_blocks, channels, sims + 1),
+        "reference_python_in_build_container": {"host": (ref or {}).get("host"), "config": name, "torch_fp32": rec["torch_fp32"] if rec else None,
+                                                "uniform_evaluator": rec["uniform"] if rec else None} if ref else None,
     }
 
 

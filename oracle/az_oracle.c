@@ -10,6 +10,7 @@
 #include "az_oracle.h"
 #include <math.h>
 #include <stdlib.h>
+#include <stddef.h>
 #include <string.h>
 
 /* ------------------------------------------------------------------ */
@@ -75,6 +76,35 @@ static int go_is_suicide(const OzState *s, int a)
     return 1;
 }
 
+/* Zobrist key of a stone (go.py:64-71 draws its table from RandomState(0); any injective-in-practice keying gives
+ * the same legality, which is what is pinned) */
+static uint64_t zkey(int color, int cell)
+{
+    uint64_t z = 0x6A09E667F3BCC909ULL + (uint64_t)(2 * cell + (color == OZ_BLACK)) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+static int go_do_move(OzState *s, int a, int color);
+
+/* AlphaZero/env/go.py:303-330.  Only points this player has played before are examined (history[0::2] for Black,
+ * [1::2] for White: the slicing assumes alternating colours and no handicap stones, as the reference does). */
+static int go_is_positional_superko(const OzState *s, int a)
+{
+    int seen = 0;
+    for (int i = s->cur == OZ_BLACK ? 0 : 1; i < s->nhist && i < OZ_SK_MAX; i += 2)
+        if (s->sk_moves[i] == a) { seen = 1; break; }
+    if (!seen) return 0;
+    static __thread OzState c;   /* too large for the stack of a deep playout recursion */
+    oz_copy(&c, s);
+    c.superko = 0;
+    go_do_move(&c, a, 0);
+    for (int i = 0; i < s->nprev && i < OZ_SK_MAX; i++)
+        if (s->sk_hash[i] == c.cur_hash) return 1;
+    return 0;
+}
+
 /* AlphaZero/env/go.py:332-355 (superko is off in self-play: game/gameplay.py:22) */
 static int go_is_legal(const OzState *s, int a)
 {
@@ -83,6 +113,7 @@ static int go_is_legal(const OzState *s, int a)
     if (s->board[a] != 0) return 0;
     if (go_is_suicide(s, a)) return 0;
     if (a == s->ko) return 0;
+    if (s->superko && go_is_positional_superko(s, a)) return 0;
     return 1;
 }
 
@@ -114,11 +145,12 @@ static int go_do_move(OzState *s, int a, int color)
     if (a != oz_pass(s)) {
         int nb[4], k, group[OZ_MAXC], ng, own[OZ_MAXC], nown;
         s->board[a] = (int8_t)color;
+        s->cur_hash ^= zkey(color, a);                       /* _update_hash, go.py:209-211 */
         k = go_nbrs(s, a, nb);
         for (int i = 0; i < k; i++) {
             int r = nb[i];
             if (s->board[r] == -color && go_chain(s, r, group, &ng) == 0) {
-                for (int j = 0; j < ng; j++) s->board[group[j]] = 0;
+                for (int j = 0; j < ng; j++) { s->board[group[j]] = 0; s->cur_hash ^= zkey(-color, group[j]); }
                 if (color == OZ_BLACK) s->pris_w += ng; else s->pris_b += ng;
                 if (ng == 1) {
                     /* go.py:542-550: evaluated right after THIS capture */
@@ -127,11 +159,15 @@ static int go_do_move(OzState *s, int a, int color)
                 }
             }
         }
+        /* previous_hashes.add(current_hash), go.py:552 (kept whether or not superko is enforced: copy() hands it on) */
+        if (s->nprev < OZ_SK_MAX) s->sk_hash[s->nprev] = s->cur_hash;
+        s->nprev++;
     } else {
         if (color == OZ_BLACK) s->passes_b++;
         if (color == OZ_WHITE) s->passes_w++;
     }
     s->cur = -color;
+    if (s->nhist < OZ_SK_MAX) s->sk_moves[s->nhist] = (int16_t)a;
     append_move(s, a);
     s->turns++;
     /* go.py:567-570 */
@@ -314,9 +350,17 @@ void oz_init(OzState *s, int game, int H, int W, int k)
     }
 }
 
+void oz_set_superko(OzState *s, int on) { s->superko = on != 0; }
+
 void oz_copy(OzState *dst, const OzState *src)
 {
-    *dst = *src;
+    /* the superko history is copied as far as it is filled, and only when a state can use it */
+    memcpy(dst, src, offsetof(OzState, sk_moves));
+    if (src->game == OZ_GO && src->superko) {
+        int nm = src->nhist < OZ_SK_MAX ? src->nhist : OZ_SK_MAX, nh = src->nprev < OZ_SK_MAX ? src->nprev : OZ_SK_MAX;
+        memcpy(dst->sk_moves, src->sk_moves, sizeof(int16_t) * (size_t)nm);
+        memcpy(dst->sk_hash, src->sk_hash, sizeof(uint64_t) * (size_t)nh);
+    }
     if (src->game == OZ_GO) {
         /* go.py:242-272: a fresh GameState() is built, so the pass counters
            and the end flag are NOT carried over */

@@ -36,6 +36,7 @@ extern "C" {
 #define OZ_MAXO 362
 #define OZ_NHIST 7
 #define OZ_NPLANES 17
+#define OZ_SK_MAX 1024
 
 enum { OZ_GO = 0, OZ_REVERSI = 1, OZ_MNK = 2 };
 #define OZ_BLACK 1
@@ -58,10 +59,18 @@ typedef struct {
     int pris_b, pris_w;             /* num_black_prisoners, num_white_prisoners */
     int stones_played;              /* reversi */
     double komi;
+    /* Positional superko (go.py:303-330; GTP play only: interface/gtp_wrapper.py:88).  Everything from here on is copied
+     * by oz_copy only as far as it is filled, and not at all when superko is 0. */
+    int superko;                    /* enforce_superko */
+    int nprev;                      /* len(previous_hashes as a list): one entry per stone move */
+    uint64_t cur_hash;              /* current_hash */
+    int16_t sk_moves[OZ_SK_MAX];    /* history (all moves, PASS included) */
+    uint64_t sk_hash[OZ_SK_MAX];    /* position hashes after every stone move so far */
 } OzState;
 
 /* ---- rules ---- */
 void oz_init(OzState *s, int game, int H, int W, int k);
+void oz_set_superko(OzState *s, int on);               /* GameState(enforce_superko=...): call on a fresh state */
 void oz_copy(OzState *dst, const OzState *src);        /* GameState.copy() semantics */
 int oz_is_legal(const OzState *s, int action);
 void oz_legal_mask(const OzState *s, uint8_t *mask /*O*/);

@@ -18,6 +18,7 @@ GO, REVERSI, MNK = 0, 1, 2
 GAME_IDS = {"go": GO, "reversi": REVERSI, "mnk": MNK}
 MAXC, MAXO, NHIST, NPLANES = 361, 362, 7, 17
 NOMOVE = -2
+SK_MAX = 1024
 
 
 def build():
@@ -36,6 +37,8 @@ class OzState(C.Structure):
         ("pris_b", C.c_int), ("pris_w", C.c_int),
         ("stones_played", C.c_int),
         ("komi", C.c_double),
+        ("superko", C.c_int), ("nprev", C.c_int), ("cur_hash", C.c_uint64),
+        ("sk_moves", C.c_int16 * SK_MAX), ("sk_hash", C.c_uint64 * SK_MAX),
     ]
 
 
@@ -123,9 +126,11 @@ def fn_ptr(name, real64=False):
 class State:
     """Thin object wrapper: actions are flat indices (x*W+y, PASS = H*W)."""
 
-    def __init__(self, game, H, W, k=0):
+    def __init__(self, game, H, W, k=0, enforce_superko=False):
         self.s = OzState()
         lib().oz_init(C.byref(self.s), GAME_IDS.get(game, game), H, W, k)
+        if enforce_superko:
+            self.s.superko = 1
 
     @property
     def H(self): return self.s.H

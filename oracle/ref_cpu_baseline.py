@@ -1,153 +1,181 @@
 """TEST / MEASUREMENT INFRASTRUCTURE - NOT PRODUCT CODE.
 
-Times the reference's own Python self-play search (/root/reference, read-only; this container only)
-on the headline workload - Go 19x19, MCTSearch._calc_move from the empty board - and writes the result
-as a data fixture, tests/golden/cpu_baseline_reference.json, that bench.py quotes beside the number it
-measures with the C port on the GPU box (the reference itself cannot travel there).
+Times the reference's own Python self-play (/root/reference, read-only; this container only) on the five named
+configurations and writes the result as a data fixture, tests/golden/cpu_baseline_reference.json, that bench.py quotes beside
+the number it measures with the C port on the GPU box (the reference itself cannot travel there).
 
-Two evaluators, both honouring the reference's evaluator contract (eval(state) -> ([(action, prob)], value)):
-  * "uniform"  - no network at all: isolates rules + search + feature cost of the reference
-  * "torch_fp32" - the fp32 PyTorch-CPU restatement of the dual-head ResNet (TensorFlow is absent),
-                   one leaf per call, as a single reference game process sees its evaluator
+Per configuration the reference's Player / MCTSearch / GameState / state_converter play games exactly as Game.start does
+(game/gameplay.py:45-71) for a fixed time, in the reference's own process shape - P single-thread game processes side by
+side (train/parallel/selfplay.py:103-108, config/rl_sys_config.yaml:27) - and as one process with all threads.  Evaluators
+(both honour eval(state) -> ([(action, prob)], value)):
+  * "torch_fp32" - the fp32 PyTorch-CPU restatement of the dual-head ResNet (TensorFlow is absent), one leaf per call
+  * "uniform"    - no network: rules + search + features of the reference alone
+The C port (oracle/port_baseline.py) runs the same shapes right after, so the reference / port ratios come from samples of
+tens of seconds taken in one session.
 
-    python oracle/ref_cpu_baseline.py [--sims 200] [--net-sims 40]
+    python oracle/ref_cpu_baseline.py [--budget 30] [--configs ttt,reversi,go9,gomoku,go19]
 """
 import argparse
 import json
+import multiprocessing as mp
 import os
 import platform
 import sys
 import time
 
-import numpy as np
-import yaml
-
-REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(HERE, ".."))
-sys.path.insert(0, REF)
-sys.dont_write_bytecode = True
-
-np.int = int
-np.float = float
-_yl = yaml.load
-yaml.load = lambda f, Loader=yaml.SafeLoader: _yl(f, Loader=Loader)
-
-import AlphaZero.env.go as go  # noqa: E402
-import AlphaZero.processing.state_converter as sc  # noqa: E402
-import AlphaZero.search.mcts as mcts  # noqa: E402
+ROOT = os.path.join(HERE, "..")
+REF = "/root/reference"
 
 
-def ttt(args):
-    """Whole tic-tac-toe games through the reference's Game class (gameplay.py:38-71), 100 sims per move, a 2-block
-    256-channel fp32 PyTorch-CPU network: the reference's own CPU-runnable configuration."""
+def ref_play_for(game, H, k, sims, blocks, channels, tt, budget_s, threads, evaluator, seed):
+    """One reference game process: games through the reference's own classes for about budget_s seconds."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    import numpy as np
+    import yaml
+    np.int = int
+    np.float = float
+    _yl = yaml.load
+    yaml.load = lambda f, Loader=yaml.SafeLoader: _yl(f, Loader=Loader)
     import torch
-    import AlphaZero.env.mnk as mnk
-    import AlphaZero.game.gameplay as gameplay
+    torch.set_num_threads(threads)
+    import AlphaZero.processing.state_converter as sc
+    import AlphaZero.player.mcts_player as mcts_player
+    import AlphaZero.search.mcts as mcts
     from alphazero_amd.network.model import random_net
     from oracle import tower_ref
-    gameplay.printlog = lambda *a, **k: None
-    with open(os.path.join(REF, "AlphaZero", "config", "mnk.yaml")) as f:
+    base = {"go": "go", "reversi": "reversi", "mnk": "mnk"}[game]
+    with open(os.path.join(REF, "AlphaZero", "config", base + ".yaml")) as f:
         cfg = yaml.load(f)
-    cfg.update(board_height=3, board_width=3, k=3, flat_move_output=9, transform_types=0)
-    mnk.game_config.update(board_height=3, board_width=3, k=3)
+    O = H * H + (0 if game == "mnk" else 1)
+    cfg.update(board_height=H, board_width=H, flat_move_output=O, transform_types=tt)
+    if game == "mnk":
+        import AlphaZero.env.mnk as env
+        cfg["k"] = k
+        env.game_config.update(board_height=H, board_width=H, k=k)
+        new_state = env.GameState
+    elif game == "reversi":
+        import AlphaZero.env.reversi as env
+        new_state = env.GameState
+    else:
+        import AlphaZero.env.go as env
+        new_state = lambda: env.GameState(size=H)  # noqa: E731
     s2t, t2a = sc.StateTensorConverter(cfg), sc.TensorActionConverter(cfg)
-    net = random_net(3, 3, 9, 2, 256, seed=0)
-    sd = net.state_dict()
+    calls = [0]
+    if evaluator == "uniform":
+        class Ev:
+            def eval(self, state):
+                calls[0] += 1
+                s2t.state_to_tensor(state)      # the reference's evaluator always converts the state
+                return t2a.tensor_to_action(np.full(O, 1.0 / O, dtype=np.float32)), np.float32(0.0)
+    else:
+        sd = random_net(H, H, O, blocks, channels, seed=0).state_dict()
 
-    class Ev:
-        def eval(self, state):
-            x = torch.from_numpy(np.ascontiguousarray(s2t.state_to_tensor(state))).float()
-            p, v = tower_ref.forward(sd, x, 2)
-            return t2a.tensor_to_action(p[0].numpy()), np.float32(v[0])
-    ext = {"player": {"max_playout": 100}, "dirichlet_before": 30, "log_iter": 10 ** 9, "max_turn": 400}
-    np.random.seed(0)
+        class Ev:
+            def eval(self, state):
+                calls[0] += 1
+                x = torch.from_numpy(np.ascontiguousarray(s2t.state_to_tensor(state))).float()
+                p, v = tower_ref.forward(sd, x, blocks)
+                return t2a.tensor_to_action(p[0].numpy()), np.float32(v[0])
+    np.random.seed(seed)
+    import random
+    random.seed(seed)
+
+    class Timeout(Exception):
+        pass
     t0 = time.perf_counter()
-    games = plies = 0
-    while time.perf_counter() - t0 < 20.0:
-        g = gameplay.Game(Ev(), Ev(), cfg, ext)
-        g.start()
-        plies += len(g.get_history()[1])
-        games += 1
-    dt = time.perf_counter() - t0
-    out = {"workload": "mnk 3x3x3 self-play through gameplay.Game, 100 sims/move, 2-block 256-ch fp32 net on CPU",
-           "games": games, "plies": plies, "seconds": dt, "moves_per_sec": plies / dt, "sims_per_sec": plies * 101 / dt,
-           "torch_threads": torch.get_num_threads(), "processes": 1}
-    print(out)
-    path = os.path.join(HERE, "..", "tests", "golden", "cpu_baseline_reference_ttt.json")
-    with open(path, "w") as f:
-        json.dump(out, f, indent=1)
+    orig_playout = mcts.MCTSearch._playout
+
+    def timed_playout(self, state, node):      # lets a long search stop at the budget (the count stays exact)
+        if node is self._root and time.perf_counter() - t0 >= budget_s:
+            raise Timeout()
+        return orig_playout(self, state, node)
+    mcts.MCTSearch._playout = timed_playout
+    plies = 0
+    try:
+        while True:
+            st = new_state()
+            p1 = mcts_player.Player(Ev(), cfg, {"max_playout": sims})
+            p2 = mcts_player.Player(Ev(), cfg, {"max_playout": sims})
+            cur = p1
+            while not (st.is_end_of_game or st.turns > 400):
+                move, _ = cur.think(st, st.turns <= 30)
+                st.do_move(move)
+                p1.ack(move); p2.ack(move)
+                cur = p2 if cur is p1 else p1
+                plies += 1
+    except Timeout:
+        pass
+    return calls[0], plies, time.perf_counter() - t0
+
+
+def _worker(args):
+    return ref_play_for(*args)
+
+
+def measure_reference(cfgt, budget_s, processes, evaluator):
+    game, H, k, sims, blocks, channels, tt = cfgt
+    ctx = mp.get_context("spawn")
+    out = {}
+    with ctx.Pool(processes) as pool:
+        res = pool.map(_worker, [(game, H, k, sims, blocks, channels, tt, budget_s, 1, evaluator, 17 * i) for i in range(processes)])
+    ev = sum(r[0] for r in res); wall = max(r[2] for r in res)
+    out["processes"] = {"n": processes, "threads_each": 1, "evals": ev, "plies": sum(r[1] for r in res), "seconds": wall,
+                        "sims_per_sec": ev / wall, "moves_per_sec": ev / wall / (sims + 1)}
+    with ctx.Pool(1) as pool:
+        e1, p1, w1 = pool.map(_worker, [(game, H, k, sims, blocks, channels, tt, budget_s, processes, evaluator, 0)])[0]
+    out["single"] = {"n": 1, "threads": processes, "evals": e1, "plies": p1, "seconds": w1, "sims_per_sec": e1 / w1,
+                     "moves_per_sec": e1 / w1 / (sims + 1)}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--sims", type=int, default=200)
-    ap.add_argument("--net-sims", type=int, default=40)
-    ap.add_argument("--blocks", type=int, default=20)
-    ap.add_argument("--ttt", action="store_true", help="the tic-tac-toe configuration (mnk 3x3x3, 100 sims, 2 blocks) instead of Go 19x19")
+    ap.add_argument("--budget", type=float, default=30.0, help="seconds per measurement")
+    ap.add_argument("--configs", default="ttt,reversi,go9,gomoku,go19")
+    ap.add_argument("--processes", type=int, default=os.cpu_count())
     args = ap.parse_args()
-    if args.ttt:
-        return ttt(args)
-    import torch
-    from alphazero_amd.network.model import random_net
-    from oracle import tower_ref
-
-    with open(os.path.join(REF, "AlphaZero", "config", "go.yaml")) as f:
-        cfg = yaml.load(f)
-    H = W = 19
-    O = H * W + 1
-    s2t = sc.StateTensorConverter(cfg)
-    t2a = sc.TensorActionConverter(cfg)
-
-    def uniform_eval(state):
-        s2t.state_to_tensor(state)  # the reference's evaluator always converts the state
-        p = np.full(O, 1.0 / O, dtype=np.float32)
-        return t2a.tensor_to_action(p), np.float32(0.0)
-
-    net = random_net(H, W, O, args.blocks, 256, seed=0)
-    sd = net.state_dict()
-    threads = torch.get_num_threads()
-
-    def torch_eval(state):
-        x = torch.from_numpy(np.ascontiguousarray(s2t.state_to_tensor(state))).float()
-        p, v = tower_ref.forward(sd, x, args.blocks)
-        return t2a.tensor_to_action(p[0].numpy()), np.float32(v[0])
-
-    out = {"workload": "Go 19x19, MCTSearch._calc_move from the empty board, Dirichlet noise on, 8 transforms",
-           "host": {"cpu": platform.processor() or platform.machine(), "cores_visible": os.cpu_count(), "torch_threads": threads},
-           "measured_with": "oracle/ref_cpu_baseline.py (reference Python search, NumPy %s)" % np.__version__}
-    for name, ev, n in (("uniform", uniform_eval, args.sims), ("torch_fp32", torch_eval, args.net_sims)):
-        np.random.seed(0)
-        search = mcts.MCTSearch(ev, cfg, max_playout=n)
-        st = go.GameState(size=19)
-        t0 = time.perf_counter()
-        search.calc_move_with_probs(st, dirichlet=True)
-        dt = time.perf_counter() - t0
-        sims = n + 1
-        out[name] = {"sims": sims, "seconds": dt, "sims_per_sec": sims / dt, "moves_per_sec_at_800": sims / dt / 801.0,
-                     "processes": 1}
-        print(name, out[name])
-    # the C port (oracle/liboracle.so) on the same host under the same two evaluators: its ratio to the reference
-    # converts a port timing taken elsewhere (the GPU box's host) into a reference-equivalent estimate
-    from oracle import oracle as oz
-
-    def port_torch(planes, O_):
-        x = torch.from_numpy(np.ascontiguousarray(planes)).float()[None]
-        p, v = tower_ref.forward(sd, x, args.blocks)
-        return p[0].numpy(), float(v[0])
-
-    for name, ev, n in (("uniform", oz.fn_ptr("oz_uniform_eval"), 20 * args.sims), ("torch_fp32", oz.make_eval(port_torch), args.net_sims)):
-        tree = oz.Tree(O, 8)
-        st = oz.State("go", H, W)
-        t0 = time.perf_counter()
-        evals = tree.search(st, n, True, ev, oz.Rng(seed=1))
-        dt = time.perf_counter() - t0
-        out["port_" + name] = {"sims": int(evals), "seconds": dt, "sims_per_sec": evals / dt}
-        out["reference_over_port_" + name] = out[name]["sims_per_sec"] / (evals / dt)
-        print("port", name, out["port_" + name], "reference/port", out["reference_over_port_" + name])
-    path = os.path.join(HERE, "..", "tests", "golden", "cpu_baseline_reference.json")
-    with open(path, "w") as f:
-        json.dump(out, f, indent=1)
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from oracle import port_baseline
+    path = os.path.join(ROOT, "tests", "golden", "cpu_baseline_reference.json")
+    try:
+        with open(path) as f:
+            out = json.load(f)
+        if "configs" not in out:
+            out = {}
+    except OSError:
+        out = {}
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = [ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")][0]
+    except (OSError, IndexError):
+        pass
+    out.update({"host": {"cpu": model or platform.processor() or platform.machine(), "cores_visible": os.cpu_count()},
+                "measured_with": "oracle/ref_cpu_baseline.py: the reference's Player/MCTSearch/GameState/state_converter (NumPy %s) and, "
+                                 "beside it, the C port (oracle/port_baseline.py); %g s per measurement" % (np.__version__, args.budget),
+                "evaluators": {"torch_fp32": "fp32 PyTorch-CPU restatement of the dual-head ResNet, one leaf per call",
+                               "uniform": "uniform priors, value 0: rules + search + features only"}})
+    out.setdefault("configs", {})
+    for name in args.configs.split(","):
+        cfgt = port_baseline.CONFIGS[name]
+        game, H, k, sims, blocks, channels, tt = cfgt
+        rec = {"workload": "%s %dx%d, %d sims/move, %d residual blocks x %d ch, transforms %d, noise on the first 31 plies"
+                           % (game, H, H, sims, blocks, channels, tt)}
+        for evaluator in ("torch_fp32", "uniform"):
+            r = measure_reference(cfgt, args.budget, args.processes, evaluator)
+            p = port_baseline.measure(cfgt, args.budget if evaluator == "torch_fp32" else min(args.budget, 10.0), args.processes, evaluator)
+            rec[evaluator] = {"reference": r, "port": p,
+                              "reference_over_port_processes": r["processes"]["sims_per_sec"] / p["processes"]["sims_per_sec"],
+                              "reference_over_port_single": r["single"]["sims_per_sec"] / p["single"]["sims_per_sec"]}
+            print(name, evaluator, "reference P-proc %.1f sims/s, single %.1f | port P-proc %.1f, single %.1f" % (
+                r["processes"]["sims_per_sec"], r["single"]["sims_per_sec"], p["processes"]["sims_per_sec"], p["single"]["sims_per_sec"]), flush=True)
+        out["configs"][name] = rec
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
     print("wrote", path)
 
 
