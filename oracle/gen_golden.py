@@ -67,9 +67,9 @@ def i2a(idx, H, W):
     return None if idx == H * W else (idx // W, idx % W)
 
 
-def make_state(game, H, W, k=None):
+def make_state(game, H, W, k=None, superko=False):
     if game == "go":
-        return go.GameState(size=H)
+        return go.GameState(size=H, enforce_superko=superko)
     if game == "reversi":
         return reversi.GameState(size=H)
     mnk.game_config.update(board_height=H, board_width=W, k=k)
@@ -95,16 +95,21 @@ def ko_idx(state, W):
 # rules traces
 # ---------------------------------------------------------------------------
 
-def rules_trace(game, H, W, k, seed, max_plies, pass_prob=0.05, moves=None, feat_every=7):
+def rules_trace(game, H, W, k, seed, max_plies, pass_prob=0.05, moves=None, feat_every=7, superko=False):
     """Random legal playout (or a given move list) through the reference rules."""
     rng = random.Random(seed)
-    st = make_state(game, H, W, k)
+    st = make_state(game, H, W, k, superko)
+    bites = 0
     conv = sc.StateTensorConverter(cfg_for(game, H, W, 8, k))
     rec = dict(moves=[], boards=[], masks=[], ko=[], cur=[], is_end=[], pris=[], passes=[], turns=[])
     feats, feat_ply, feat_tid = [], [], []
     ply = 0
     while not st.is_end_of_game and ply < max_plies:
         mask = legal_mask(st, game, H, W)
+        if superko:   # how often positional superko (go.py:303-330) forbids what the other rules allow
+            st.enforce_superko = False
+            bites += int((legal_mask(st, game, H, W) != mask).sum())
+            st.enforce_superko = True
         rec["masks"].append(mask)
         rec["boards"].append(np.array(st.board, dtype=np.int8))
         rec["ko"].append(ko_idx(st, W))
@@ -151,7 +156,7 @@ def rules_trace(game, H, W, k, seed, max_plies, pass_prob=0.05, moves=None, feat
         final_board=np.array(st.board, np.int8), final_ko=ko_idx(st, W),
         final_winner=2 if w is None else int(w), final_is_end=int(st.is_end_of_game),
         feats=np.array(feats, np.int8), feat_ply=np.array(feat_ply, np.int32),
-        feat_tid=np.array(feat_tid, np.int32),
+        feat_tid=np.array(feat_tid, np.int32), superko=int(superko), superko_bites=bites,
     )
     return out
 
@@ -409,9 +414,26 @@ def main_match():
     mnk.game_config.update(board_height=6, board_width=5, k=4)
 
 
+def main_superko():
+    """Positional superko (enforce_superko=True, what the GTP front end plays with: interface/gtp_wrapper.py:88): long random
+    games on small boards, where captured stones are replayed often enough for the rule to bite."""
+    total = 0
+    for H, seeds, plies, pp in ((3, range(100, 140), 300, 0.0), (4, range(200, 240), 600, 0.005), (5, range(300, 330), 800, 0.005)):
+        best = sorted(((rules_trace("go", H, H, None, sd, plies, pass_prob=pp, feat_every=10 ** 9, superko=True)) for sd in seeds),
+                      key=lambda d: -d["superko_bites"])[:2]
+        for i, d in enumerate(best):
+            print("rulesko_go%d_%d" % (H, i), "plies", len(d["moves"]), "superko-forbidden points", d["superko_bites"])
+            total += d["superko_bites"]
+            save("rulesko_go%d_%d" % (H, i), d)
+    assert total >= 10
+    save("rulesko_go7", rules_trace("go", 7, 7, None, 93, 900, pass_prob=0.01, feat_every=10 ** 9, superko=True))
+
+
 def main():
     if "--only64" in sys.argv:
         return main64()
+    if "--only-superko" in sys.argv:
+        return main_superko()
     if "--only-match" in sys.argv:
         return main_match()
     if "--only-shapes" in sys.argv:
@@ -488,6 +510,7 @@ def main():
     save("search_go19", search_trace("go19", "go", 19, 19, None, 8, 30, 30, 400, 27, 6))
     main64()
     main_match()
+    main_superko()
 
 
 if __name__ == "__main__":

@@ -8,10 +8,15 @@ from oracle.fake_eval import fake_eval_planes
 from tests.helpers import golden_names, load_golden
 
 
-@pytest.mark.parametrize("name", golden_names("rules_"))
+@pytest.mark.parametrize("name", golden_names("rules_") + golden_names("rulesko_"))
 def test_rules_trace(name):
+    """rulesko_*: games the reference played with enforce_superko=True (positional superko, env/go.py:303-330); their
+    masks forbid points that the other rules allow (superko_bites of them)."""
     g = load_golden(name)
-    st = oz.State(str(g["game"]), int(g["H"]), int(g["W"]), int(g["k"]))
+    superko = bool(g.get("superko", 0))
+    st = oz.State(str(g["game"]), int(g["H"]), int(g["W"]), int(g["k"]), enforce_superko=superko)
+    if superko and not name.endswith("go7"):
+        assert g["superko_bites"] > 0
     fi = 0
     for ply in range(len(g["boards"])):
         assert np.array_equal(st.board(), g["boards"][ply]), (name, ply)
