@@ -25,7 +25,7 @@ class AzConfig(C.Structure):
         ("rng_replay", C.c_int32), ("seed", C.c_uint64), ("record_trajectories", C.c_int32),
         ("num_blocks", C.c_int32), ("channels", C.c_int32), ("tower_dtype", C.c_int32), ("device", C.c_int32),
         ("leaves_per_round", C.c_int32), ("virtual_loss", C.c_double),
-        ("tree_full_policy", C.c_int32), ("search_f64", C.c_int32),
+        ("tree_full_policy", C.c_int32), ("search_f64", C.c_int32), ("enforce_superko", C.c_int32),
     ]
 
 

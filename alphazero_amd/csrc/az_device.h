@@ -18,7 +18,10 @@ enum { G_GO = 0, G_REVERSI = 1, G_MNK = 2 };
 // int32 scalars of one game state, one 64-byte line per slot
 enum {
     S_HEAD = 0, S_CUR, S_KO, S_TURNS, S_NHIST, S_LAST1, S_LAST2, S_END, S_WIN, S_WINSET,
-    S_PB, S_PW, S_PRB, S_PRW, S_STONES, S_PAD, S_N
+    S_PB, S_PW, S_PRB, S_PRW, S_STONES,
+    S_NPREV,                      // positional superko: positions recorded so far (one per stone move)
+    S_H0A, S_H0B, S_H1A, S_H1B,   // 128-bit hash of the current position, as four 32-bit words
+    S_N = 32
 };
 
 // search machine phases of a slot
@@ -33,11 +36,23 @@ enum {
 
 struct Geo {
     int game, H, W, NC, O, k;
+    int superko;   // Go: enforce positional superko (env/go.py:303-330; the reference's GTP games)
+};
+
+// Per-slot record that positional superko needs: every move of the game (PASS included) and the hash of the position
+// after every stone move.  A playout appends behind the game's own entries and leaves the game's counts untouched, so
+// what it wrote is simply overwritten later.
+struct SK {
+    int16_t *moves;              // [cap]
+    unsigned long long *hash;    // [cap][2]
+    int cap;
 };
 
 struct PS {  // wave-uniform scalars of a (playout) state
     int head, cur, ko, turns, nhist, last1, last2, is_end, winner, winner_set;
     int passes_b, passes_w, pris_b, pris_w, stones;
+    int nprev;
+    unsigned long long h0, h1;
 };
 
 struct __align__(16) WLds {
@@ -100,7 +115,20 @@ struct Dev {
     // largest number of edges / expanded nodes any tree has held since the counters were reset: AZ_CTR_BUCKETS pairs,
     // a workgroup raises the pair of its bucket (the host takes the maximum)
     int32_t *peak;
+    // positional superko (geo.superko): move and position-hash history per slot
+    int16_t *sk_moves;             // [G][sk_cap]
+    unsigned long long *sk_hash;   // [G][sk_cap][2]
+    int sk_cap;
 };
+
+__device__ __forceinline__ SK slot_sk(const Dev &D, int g)
+{
+    SK k;
+    k.moves = D.sk_moves ? D.sk_moves + (size_t)g * D.sk_cap : nullptr;
+    k.hash = D.sk_hash ? D.sk_hash + (size_t)g * D.sk_cap * 2 : nullptr;
+    k.cap = D.sk_cap;
+    return k;
+}
 
 #define WSYNC() __syncthreads()
 
@@ -124,6 +152,23 @@ __device__ __forceinline__ int wave_sum(int v)
     return v;
 }
 
+__device__ __forceinline__ unsigned long long wave_xor(unsigned long long v)
+{
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo ^= __shfl_xor(lo, o, 64); hi ^= __shfl_xor(hi, o, 64); }
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// 128-bit key of a stone of `color` on `cell` (the reference keeps a 64-bit Zobrist table, env/go.py:64-71; what matters
+// is that equal positions hash equally and different ones practically never do)
+__device__ __forceinline__ void zkey(int color, int cell, unsigned long long &a, unsigned long long &b)
+{
+    const unsigned long long k = (unsigned long long)(2 * cell + (color == 1));
+    a = mix64(0x6A09E667F3BCC909ULL + k * 0x9E3779B97F4A7C15ULL);
+    b = mix64(0xBB67AE8584CAA73BULL ^ (k * 0xD6E8FEB86659FD93ULL + a));
+}
+
 __device__ __forceinline__ int8_t *cur_board(WLds &L, const PS &s) { return L.ring[s.head & 7]; }
 // board_history[t], t = 0 (oldest) .. 6 (newest); t = 7 is the current board
 __device__ __forceinline__ int8_t *hist_board(WLds &L, const PS &s, int t) { return L.ring[(s.head + 1 + t) & 7]; }
@@ -135,6 +180,9 @@ __device__ __forceinline__ void load_scalars(const Dev &D, int g, PS &s)
     s.nhist = sc[S_NHIST]; s.last1 = sc[S_LAST1]; s.last2 = sc[S_LAST2]; s.is_end = sc[S_END];
     s.winner = sc[S_WIN]; s.winner_set = sc[S_WINSET]; s.passes_b = sc[S_PB]; s.passes_w = sc[S_PW];
     s.pris_b = sc[S_PRB]; s.pris_w = sc[S_PRW]; s.stones = sc[S_STONES];
+    s.nprev = sc[S_NPREV];
+    s.h0 = ((unsigned long long)(unsigned)sc[S_H0B] << 32) | (unsigned)sc[S_H0A];
+    s.h1 = ((unsigned long long)(unsigned)sc[S_H1B] << 32) | (unsigned)sc[S_H1A];
 }
 
 __device__ __forceinline__ void store_scalars(const Dev &D, int g, const PS &s)
@@ -145,6 +193,9 @@ __device__ __forceinline__ void store_scalars(const Dev &D, int g, const PS &s)
         sc[S_NHIST] = s.nhist; sc[S_LAST1] = s.last1; sc[S_LAST2] = s.last2; sc[S_END] = s.is_end;
         sc[S_WIN] = s.winner; sc[S_WINSET] = s.winner_set; sc[S_PB] = s.passes_b; sc[S_PW] = s.passes_w;
         sc[S_PRB] = s.pris_b; sc[S_PRW] = s.pris_w; sc[S_STONES] = s.stones;
+        sc[S_NPREV] = s.nprev;
+        sc[S_H0A] = (int)(unsigned)s.h0; sc[S_H0B] = (int)(unsigned)(s.h0 >> 32);
+        sc[S_H1A] = (int)(unsigned)s.h1; sc[S_H1B] = (int)(unsigned)(s.h1 >> 32);
     }
 }
 
@@ -302,7 +353,7 @@ __device__ __forceinline__ int go_chain_libs(WLds &L, int cell) { return L.libs[
 // legal mask -> L.mask[0..O), returns number of legal actions
 // ---------------------------------------------------------------------------
 
-__device__ int dev_legal_mask(const Geo &G, WLds &L, const PS &s)
+__device__ int dev_legal_mask(const Geo &G, WLds &L, const PS &s, const SK *sk = nullptr)
 {
     const int lane = lane_id();
     const int W = G.W, H = G.H, NC = G.NC;
@@ -324,7 +375,24 @@ __device__ int dev_legal_mask(const Geo &G, WLds &L, const PS &s)
             open[j] = empty && o;
             need |= empty && !o;
         }
-        const bool labelled = __any(need);
+        // positional superko looks only at points the player to move has played before (history[0::2] for Black,
+        // [1::2] for White, go.py:314-322): flag them, one pass over the move list
+        uint8_t *const played = reinterpret_cast<uint8_t *>(L.cum);
+        int sk_any = 0;
+        if (G.superko && sk) {
+            for (int i = lane; i < AZ_CP; i += AZ_WAVE) played[i] = 0;
+            WSYNC();
+            const int nh = min(s.nhist, sk->cap);
+            for (int i = (s.cur == 1 ? 0 : 1) + 2 * lane; i < nh; i += 2 * AZ_WAVE) {
+                const int m = sk->moves[i];
+                if (m >= 0 && m < NC) played[m] = 1;
+            }
+            WSYNC();
+#pragma unroll
+            for (int j = 0; j < AZ_NJ; j++) sk_any |= (gc.info[j] & 16u) && go_col(gc, j) == 0 && played[gc.idx[j]];
+            sk_any = __any(sk_any);
+        }
+        const bool labelled = __any(need) || sk_any;
         if (labelled) go_label(G, L, gc);
 #pragma unroll
         for (int j = 0; j < AZ_NJ; j++) {
@@ -345,6 +413,38 @@ __device__ int dev_legal_mask(const Geo &G, WLds &L, const PS &s)
                 }
             }
             if (i == s.ko) legal = 0;
+            if (sk_any) {
+                // every otherwise legal point the player has played before is played out: the position it leads to
+                // (stone placed, opposing chains whose last liberty it was removed) may not have occurred already
+                unsigned long long cand = __ballot(legal && (i < NC) && played[gc.idx[j]]);
+                while (cand) {
+                    const int src = __ffsll((long long)cand) - 1;
+                    cand &= cand - 1;
+                    const int a = src + j * AZ_WAVE;
+                    const int ax = a / W, ay = a - ax * W;
+                    int cap[4] = {-1, -1, -1, -1};
+                    if (ax > 0 && b[a - W] == -s.cur && L.libs[L.label[a - W]] == 1) cap[0] = L.label[a - W];
+                    if (ax + 1 < H && b[a + W] == -s.cur && L.libs[L.label[a + W]] == 1) cap[1] = L.label[a + W];
+                    if (ay > 0 && b[a - 1] == -s.cur && L.libs[L.label[a - 1]] == 1) cap[2] = L.label[a - 1];
+                    if (ay + 1 < W && b[a + 1] == -s.cur && L.libs[L.label[a + 1]] == 1) cap[3] = L.label[a + 1];
+                    unsigned long long x0 = 0, x1 = 0;
+                    for (int c = lane; c < NC; c += AZ_WAVE) {
+                        const int lb = L.label[c];
+                        if (b[c] == -s.cur && (lb == cap[0] || lb == cap[1] || lb == cap[2] || lb == cap[3])) {
+                            unsigned long long k0, k1;
+                            zkey(-s.cur, c, k0, k1);
+                            x0 ^= k0; x1 ^= k1;
+                        }
+                    }
+                    unsigned long long k0, k1;
+                    zkey(s.cur, a, k0, k1);
+                    const unsigned long long r0 = s.h0 ^ k0 ^ wave_xor(x0), r1 = s.h1 ^ k1 ^ wave_xor(x1);
+                    int hit = 0;
+                    const int np = min(s.nprev, sk->cap);
+                    for (int q = lane; q < np; q += AZ_WAVE) hit |= sk->hash[2 * q] == r0 && sk->hash[2 * q + 1] == r1;
+                    if (__any(hit) && lane == src) legal = 0;
+                }
+            }
             if (i < NC) L.mask[i] = (uint8_t)legal;
             count += __popcll(__ballot(legal));
         }
@@ -386,12 +486,13 @@ __device__ int dev_legal_mask(const Geo &G, WLds &L, const PS &s)
 // do_move for a move already known to be legal
 // ---------------------------------------------------------------------------
 
-__device__ void dev_do_move(const Geo &G, WLds &L, PS &s, int a)
+__device__ void dev_do_move(const Geo &G, WLds &L, PS &s, int a, const SK *sk = nullptr)
 {
     const int lane = lane_id();
     const int W = G.W, H = G.H, NC = G.NC;
     const int color = s.cur;
     if (G.game == G_GO) {
+        if (G.superko && sk && lane == 0 && s.nhist < sk->cap) sk->moves[s.nhist] = (int16_t)a;
         s.ko = -1;
         push_history(L, s);
         int8_t *b = cur_board(L, s);
@@ -406,6 +507,7 @@ __device__ void dev_do_move(const Geo &G, WLds &L, PS &s, int a)
             for (int q = 0; q < n; q++) hostile |= b[nb[q]] == -color;
             if (lane == 0) b[a] = (int8_t)color;
             WSYNC();
+            unsigned long long rx0 = 0, rx1 = 0;   // keys of the stones this move takes off (superko hash)
             // a stone that touches no opposing stone captures nothing and marks no ko (the move is known to be legal,
             // so it is no suicide either): the chains only have to be labelled for a contact move
             if (hostile) {
@@ -441,11 +543,23 @@ __device__ void dev_do_move(const Geo &G, WLds &L, PS &s, int a)
 #pragma unroll
             for (int j = 0; j < AZ_NJ; j++) {
                 int i = lane + j * AZ_WAVE;
-                if (rem[j]) b[i] = 0;
+                if (rem[j]) {
+                    b[i] = 0;
+                    if (G.superko) { unsigned long long k0, k1; zkey(-color, i, k0, k1); rx0 ^= k0; rx1 ^= k1; }
+                }
             }
             WSYNC();
             if (color == 1) s.pris_w += removed; else s.pris_b += removed;
             s.ko = ko;
+            }
+            if (G.superko) {
+                // current_hash after the move and its captures; previous_hashes.add(current_hash) (go.py:552)
+                unsigned long long k0, k1;
+                zkey(color, a, k0, k1);
+                s.h0 ^= k0 ^ wave_xor(rx0); s.h1 ^= k1 ^ wave_xor(rx1);
+                if (sk && lane == 0 && s.nprev < sk->cap) { sk->hash[2 * s.nprev] = s.h0; sk->hash[2 * s.nprev + 1] = s.h1; }
+                s.nprev++;
+                WSYNC();
             }
         } else {
             if (color == 1) s.passes_b++; else s.passes_w++;

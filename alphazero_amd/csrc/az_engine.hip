@@ -236,6 +236,7 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     memset(&D, 0, sizeof(D));
     D.geo.game = cfg->game; D.geo.H = H; D.geo.W = W; D.geo.NC = NC; D.geo.k = cfg->k;
     D.geo.O = NC + (cfg->game == AZ_MNK ? 0 : 1);
+    D.geo.superko = (cfg->game == AZ_GO && cfg->enforce_superko) ? 1 : 0;
     const int G = cfg->n_slots, O = D.geo.O;
     D.G = G;
     D.max_playout = cfg->max_playout;
@@ -296,6 +297,11 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     A(tr_winner, int32_t, G);
     A(ctr, unsigned long long, (size_t)AZ_CTR_BUCKETS * (C_N + 1));
     A(peak, int32_t, (size_t)AZ_CTR_BUCKETS * 2);
+    if (D.geo.superko) {
+        D.sk_cap = std::max(cfg->max_turn + 2, 1024) + D.MAXD;
+        A(sk_moves, int16_t, (size_t)G * D.sk_cap);
+        A(sk_hash, unsigned long long, (size_t)G * D.sk_cap * 2);
+    }
 #undef A
 #undef AR
     const size_t stn = std::max(G, 64);
@@ -370,6 +376,14 @@ extern "C" int az_state_copy(az_engine *dst, int32_t ds, az_engine *src, int32_t
     if (dst->D.geo.game != src->D.geo.game || dst->D.geo.H != src->D.geo.H || dst->D.geo.W != src->D.geo.W ||
         dst->cfg.device != src->cfg.device)
         return set_err(h, AZ_ERR_ARG, "engines differ in game, board or device");
+    if (dst->D.geo.superko) {
+        if (!src->D.geo.superko) return set_err(h, AZ_ERR_ARG, "a superko engine needs the move record of a superko source");
+        int32_t nh = 0;
+        HIPCHK(hipSetDevice(h->cfg.device));
+        HIPCHK(hipStreamSynchronize(src->stream));
+        HIPCHK(hipMemcpy(&nh, src->D.sc + (size_t)ss * S_N + S_NHIST, 4, hipMemcpyDeviceToHost));
+        if (nh + dst->D.MAXD > dst->D.sk_cap) return set_err(h, AZ_ERR_ARG, "the game is too long for the destination's superko record");
+    }
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(src->stream));
     hipLaunchKernelGGL(k_state_copy, dim3(1), dim3(64), 0, dst->stream, dst->D, ds, src->D, ss, ref);
@@ -409,6 +423,18 @@ extern "C" int az_state_set(az_engine *h, int32_t slot, const az_state_blob *in)
     sc[S_NHIST] = in->n_history; sc[S_LAST1] = in->last1; sc[S_LAST2] = in->last2; sc[S_END] = in->is_end_of_game;
     sc[S_WIN] = in->winner; sc[S_WINSET] = in->winner_set; sc[S_PB] = in->passes_black; sc[S_PW] = in->passes_white;
     sc[S_PRB] = in->num_black_prisoners; sc[S_PRW] = in->num_white_prisoners; sc[S_STONES] = in->stones_played;
+    if (h->D.geo.superko) {
+        // the blob carries no move list: the slot's own superko record stays valid only if the blob describes the same
+        // game at the same length (a caller that edits scalars such as current_player); a fresh game starts it anew
+        int32_t old[S_N];
+        HIPCHK(hipMemcpyAsync(old, h->D.sc + (size_t)slot * S_N, sizeof old, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (in->n_history == old[S_NHIST]) {
+            for (int k = S_NPREV; k <= S_H1B; k++) sc[k] = old[k];
+        } else if (in->n_history != 0) {
+            return set_err(h, AZ_ERR_ARG, "az_state_set on a superko engine: the blob's history differs from the slot's (no move list to restore)");
+        }
+    }
     HIPCHK(hipMemcpyAsync(h->D.ring + (size_t)slot * 8 * AZ_CP, ring, sizeof ring, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->D.sc + (size_t)slot * S_N, sc, sizeof sc, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

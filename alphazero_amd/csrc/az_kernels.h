@@ -166,6 +166,7 @@ __device__ __forceinline__ void select_one(const Dev &D, const int sub, WLds &L)
     PS s;
     load_scalars(D, g, s);
     load_ring(D, g, L);
+    const SK sk = slot_sk(D, g);   // superko record: the playout appends behind the game's entries
     if (G.game == G_GO) { s.is_end = 0; s.passes_b = 0; s.passes_w = 0; }  // GameState.copy(), env/go.py:242
 
     int root_expand = 0;
@@ -244,7 +245,7 @@ __device__ __forceinline__ void select_one(const Dev &D, const int sub, WLds &L)
             const int wl = bi & (AZ_WAVE - 1);  // child c sits in lane c % 64
             int a = __shfl(myAct, wl, 64);
             SEL_STAMP(2);  // child scan + arg-max
-            dev_do_move(G, L, s, a);
+            dev_do_move(G, L, s, a, &sk);
             SEL_STAMP(3);  // rule move
             int N = __shfl(bN, wl, 64) + 1;  // child.visit()
             WSYNC();
@@ -265,7 +266,7 @@ __device__ __forceinline__ void select_one(const Dev &D, const int sub, WLds &L)
 
     // leaf: transform id, legality on the un-transformed state, evaluator input
     SEL_STAMP(5);
-    int nlegal = dev_legal_mask(G, L, s);
+    int nlegal = dev_legal_mask(G, L, s, &sk);
     SEL_STAMP(6);  // legal mask
     uint8_t *gm = D.leaf_mask + (size_t)li * AZ_OP;
     for (int i = lane; i < AZ_OP / 4; i += AZ_WAVE)
@@ -513,7 +514,8 @@ __global__ __launch_bounds__(64) void k_move(Dev D)
     PS s;
     load_scalars(D, g, s);
     load_ring(D, g, L);
-    dev_do_move(G, L, s, mv);
+    const SK sk = slot_sk(D, g);
+    dev_do_move(G, L, s, mv, &sk);
     store_ring(D, g, L);
     store_scalars(D, g, s);
     int over = s.is_end || s.turns > D.max_turn;
@@ -674,7 +676,7 @@ __device__ __forceinline__ void init_state(const Geo &G, WLds &L, PS &s)
     WSYNC();
     s.head = 0; s.cur = 1; s.ko = -1; s.turns = 0; s.nhist = 0; s.last1 = NOMOVE; s.last2 = NOMOVE;
     s.is_end = 0; s.winner = 0; s.winner_set = 0; s.passes_b = 0; s.passes_w = 0; s.pris_b = 0; s.pris_w = 0;
-    s.stones = 0;
+    s.stones = 0; s.nprev = 0; s.h0 = 0; s.h1 = 0;
     if (G.game == G_REVERSI) {  // env/reversi.py:20-23
         int h = G.H / 2;
         if (lane_id() == 0) {
@@ -719,7 +721,8 @@ __global__ __launch_bounds__(64) void k_rules_mask(Dev D, const int32_t *slots, 
     PS s;
     load_scalars(D, g, s);
     load_ring(D, g, L);
-    dev_legal_mask(D.geo, L, s);
+    const SK sk = slot_sk(D, g);
+    dev_legal_mask(D.geo, L, s, &sk);
     for (int i = lane_id(); i < D.geo.O; i += AZ_WAVE) out[(size_t)q * D.geo.O + i] = L.mask[i];
 }
 
@@ -735,14 +738,19 @@ __global__ __launch_bounds__(64) void k_rules_domove(Dev D, const int32_t *slots
     load_ring(D, g, L);
     int color = colors ? colors[q] : 0;
     if (color != 0) s.cur = color;  // legality is judged for the stated colour (env/go.py:511-514)
-    dev_legal_mask(D.geo, L, s);
+    const SK sk = slot_sk(D, g);
+    dev_legal_mask(D.geo, L, s, &sk);
     int ok = a >= 0 && a < D.geo.O && L.mask[a];
     WSYNC();
     if (!ok) {
         if (lane_id() == 0) { status[q] = -3; ended[q] = s.is_end; }
         return;
     }
-    dev_do_move(D.geo, L, s, a);
+    if (D.geo.superko && s.nhist >= D.sk_cap) {   // the superko record of this slot is full: the move is refused, not forgotten
+        if (lane_id() == 0) { status[q] = -7; ended[q] = s.is_end; }
+        return;
+    }
+    dev_do_move(D.geo, L, s, a, &sk);
     store_ring(D, g, L);
     store_scalars(D, g, s);
     if (lane_id() == 0) { status[q] = 0; ended[q] = s.is_end; }
@@ -799,6 +807,11 @@ __global__ __launch_bounds__(64) void k_state_copy(Dev Dd, int gd, Dev Ds, int g
     load_scalars(Ds, gs, s);
     load_ring(Ds, gs, L);
     if (ref_semantics && Ds.geo.game == G_GO) { s.is_end = 0; s.passes_b = 0; s.passes_w = 0; }
+    if (Dd.geo.superko) {   // copy() hands the move list and previous_hashes on (go.py:247-253); the host checked the sizes
+        const SK a = slot_sk(Ds, gs), b = slot_sk(Dd, gd);
+        for (int i = lane_id(); i < min(s.nhist, b.cap); i += AZ_WAVE) b.moves[i] = a.moves[i];
+        for (int i = lane_id(); i < 2 * min(s.nprev, b.cap); i += AZ_WAVE) b.hash[i] = a.hash[i];
+    }
     store_ring(Dd, gd, L);
     store_scalars(Dd, gd, s);
 }

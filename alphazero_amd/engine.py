@@ -45,13 +45,14 @@ class Engine:
                  dirichlet_before=30, max_turn=400, d_alpha=0.03, d_epsilon=0.25, tree_edge_cap=0, tree_block_cap=0,
                  max_depth=0, rng_replay=False, seed=0, record_trajectories=False, num_blocks=0, channels=256,
                  tower_dtype="bf16", device=0, search_f64=False, tree_full_policy=0, leaves_per_round=1,
-                 virtual_loss=1.0):
+                 virtual_loss=1.0, enforce_superko=False):
         self._L = _lib.lib()
         cfg = AzConfig(GAME_IDS[game] if isinstance(game, str) else int(game), board_height, board_width, k, n_slots,
                        max_playout, transform_types, dirichlet_before, max_turn, d_alpha, d_epsilon, tree_edge_cap,
                        tree_block_cap, max_depth, int(rng_replay), seed, int(record_trajectories), num_blocks, channels,
                        {"fp32": 0, "bf16": 1}[tower_dtype] if isinstance(tower_dtype, str) else int(tower_dtype), device,
-                       int(leaves_per_round), float(virtual_loss), int(tree_full_policy), int(bool(search_f64)))
+                       int(leaves_per_round), float(virtual_loss), int(tree_full_policy), int(bool(search_f64)),
+                       int(bool(enforce_superko)))
         self.cfg = cfg
         # dtype of W / P / priors / values: float64 reproduces a search fed by a float64 evaluator (dummy_eval.py:26-28)
         self.real = np.float64 if search_f64 else np.float32

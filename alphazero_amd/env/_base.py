@@ -19,8 +19,9 @@ _POOL_SLOTS = 256
 class _SlotPool:
     """Rules-only engines (no trees, no tower) whose slots back GameState objects."""
 
-    def __init__(self, game, H, W, k):
+    def __init__(self, game, H, W, k, superko=False):
         self.key = (game, H, W, k)
+        self.superko = superko
         self.engines = []
         self.free = []
 
@@ -28,7 +29,7 @@ class _SlotPool:
         if not self.free:
             game, H, W, k = self.key
             eng = Engine(game, H, W, k, n_slots=_POOL_SLOTS, max_playout=0, transform_types=8 if H == W else 0,
-                         tree_edge_cap=1, tree_block_cap=2, max_depth=2)
+                         tree_edge_cap=1, tree_block_cap=2, max_depth=2, enforce_superko=self.superko)
             self.engines.append(eng)
             self.free.extend((eng, s) for s in reversed(range(_POOL_SLOTS)))
         return self.free.pop()
@@ -40,22 +41,22 @@ class _SlotPool:
 _pools = {}
 
 
-def _pool(game, H, W, k):
-    key = (game, H, W, k)
+def _pool(game, H, W, k, superko=False):
+    key = (game, H, W, k, bool(superko))
     if key not in _pools:
-        _pools[key] = _SlotPool(*key)
+        _pools[key] = _SlotPool(game, H, W, k, bool(superko))
     return _pools[key]
 
 
 class BaseGameState(object):
     _game = None
 
-    def _setup(self, H, W, k=0, history_length=8):
+    def _setup(self, H, W, k=0, history_length=8, superko=False):
         if history_length != 8:
             raise ValueError("the engine keeps history_length = 8 boards (config history_step)")
         self.height, self.width = H, W
         self._k = k
-        self._pool = _pool(self._game, H, W, k)
+        self._pool = _pool(self._game, H, W, k, superko)
         self._eng, self._slot = self._pool.acquire()
         self._eng.reset([self._slot])
         self._blob = None
@@ -148,6 +149,8 @@ class BaseGameState(object):
         if idx < 0:
             raise IllegalMove(str(action))
         status, ended = self._eng.do_move([self._slot], [idx], None if color is None else [int(color)])
+        if status[0] == -7:
+            raise RuntimeError("the game is longer than the engine's superko record")
         if status[0] != 0:
             raise IllegalMove(str(action))
         self._dirty()

@@ -3,22 +3,31 @@ from ._base import BLACK, EMPTY, PASS_MOVE, WHITE, BaseGameState, IllegalMove  #
 
 
 class GameState(BaseGameState):
-    """Go rules on the engine (env/go.py:11-594).  Positional superko (GTP only) is not offered."""
+    """Go rules on the engine (env/go.py:11-594), with positional superko on request (env/go.py:303-330: what the
+    reference's GTP front end plays with; self-play leaves it off)."""
     _game = "go"
 
     def __init__(self, size=19, komi=7.5, enforce_superko=False, history_length=8):
-        if enforce_superko:
-            raise NotImplementedError("enforce_superko is only used by the reference's GTP front end")
         if komi != 7.5:
             raise NotImplementedError("the engine scores with komi 7.5")
         self.size = size
         self.komi = komi
-        self.enforce_superko = False
+        self._superko = bool(enforce_superko)
         self.handicaps = []
-        self._setup(size, size, 0, history_length)
+        self._setup(size, size, 0, history_length, superko=self._superko)
+
+    @property
+    def enforce_superko(self):
+        return self._superko
+
+    @enforce_superko.setter
+    def enforce_superko(self, on):
+        if bool(on) != self._superko:
+            raise NotImplementedError("enforce_superko is fixed when the state is created (it selects the engine that keeps "
+                                      "the position history)")
 
     def copy(self):
-        return self._copy_into(GameState(self.size, self.komi))
+        return self._copy_into(GameState(self.size, self.komi, self._superko))
 
     @property
     def ko(self):

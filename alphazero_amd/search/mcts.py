@@ -91,6 +91,7 @@ class MCTSearch(object):
         self._K = max(1, int(leaves_per_round))
         self._eng = Engine(**self._eng_kw, **tower_kw)
         self._loaded_version = None
+        self._searched = False
         # Arithmetic of N/W/P follows the evaluator's output type, as NumPy's promotion makes it in the reference:
         # float32 priors (the network) keep the search in float32, Python floats / float64 (DummyEvaluator) in
         # float64.  Decided by the first evaluation of a host evaluator; the device tower is always float32.
@@ -107,6 +108,19 @@ class MCTSearch(object):
         return self._H * self._W if action is None else action[0] * self._W + action[1]
 
     def _calc_move(self, state, dirichlet=False):
+        if bool(getattr(state, "enforce_superko", False)) != bool(self._eng_kw.get("enforce_superko", False)):
+            # the search plays by the state's rules (copy() hands enforce_superko on to every playout, env/go.py:250):
+            # the first search decides which engine holds the tree
+            if self._searched:
+                raise ValueError("enforce_superko changed between searches of one tree")
+            self._eng.close()
+            self._eng_kw["enforce_superko"] = bool(state.enforce_superko)
+            tower_kw = {}
+            if self._tower is not None:
+                tower_kw = dict(num_blocks=self._tower.num_blocks, channels=self._tower.channels, tower_dtype=self._tower.dtype)
+            self._eng = Engine(**self._eng_kw, **tower_kw)
+            self._loaded_version = None
+        self._searched = True
         eng = self._eng
         eng.state_copy(0, state._eng, state._slot, ref_semantics=False)
         _, n_children, _, _, _ = eng.root_stats(0, 0)

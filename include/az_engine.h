@@ -81,6 +81,10 @@ typedef struct az_config {
     int32_t search_f64;        /* 0: N/W/P arithmetic in float32 (a float32 evaluator: the network, nn_eval_parallel.py:75-92);
                                   1: in float64 (an evaluator returning Python floats / float64: evaluator/dummy_eval.py:26-28).
                                   With 1 the tower cannot feed the search; use the *_f64 entry points */
+    int32_t enforce_superko;   /* Go: GameState(enforce_superko=True), positional superko (env/go.py:303-330) in the rules entry
+                                  points and inside the search, as the reference's GTP games run (interface/gtp_wrapper.py:88);
+                                  self-play runs without it (game/gameplay.py:22).  A slot then keeps its move list and the
+                                  hash of every position, up to max(max_turn + 2, 1024) + max_depth moves */
 } az_config;
 
 /* Fixed-layout copy of one game state (attributes of env/*.py GameState). */

@@ -421,3 +421,39 @@ def test_batched_selfplay_keeps_surplus_games_and_drains_for_new_weights():
     for s, p, r in first + second + third:
         assert 5 <= s.shape[0] <= 9 and np.allclose(p.sum(axis=1), 1.0)
     mnk.game_config.update(board_height=6, board_width=5, k=4)
+
+
+def test_play_cmd_shaped_game_on_the_device_tower():
+    """The loop of play_cmd.py:64-108 (raw network player aside): GameState(), two MCTS players on a network evaluator,
+    think(state) called with ONE positional argument, the board read as a 2-D array of {1, -1, 0} for printing
+    (play_cmd.py:55-61,86), do_move, both players ack, get_winner at the end - with positional superko switched on as the
+    GTP front end does (interface/gtp_wrapper.py:88), on a 5x5 board so that the game ends within the test."""
+    import alphazero_amd.env.go as go
+    from alphazero_amd.evaluator.nn_eval import NNEvaluator
+    from alphazero_amd.player.mcts_player import Player
+    H = 5
+    cfg = _cfg("go", H, H, H * H + 1, 8)
+    ev = NNEvaluator(cfg, num_blocks=1, channels=128, dtype="bf16", max_batch_size=4, seed=3)
+    players = [Player(ev, cfg, {"max_playout": 24}), Player(ev, cfg, {"max_playout": 24})]
+    state = go.GameState(size=H, enforce_superko=True)
+    seen = set()
+    cur = 0
+    for ply in range(60):
+        if state.is_end_of_game:
+            break
+        rows = ["".join({1: "X", -1: "O", 0: "."}[int(v)] for v in row) for row in state.board]   # print_board reads state.board
+        assert len(rows) == H and all(len(r) == H for r in rows)
+        move, probs = players[cur].think(state)                 # one positional argument, tuple back
+        assert state.is_legal(move) and abs(sum(p for _, p in probs) - 1.0) < 1e-9
+        state.do_move(move)
+        if move is not go.PASS_MOVE:
+            key = np.asarray(state.board).tobytes()
+            assert key not in seen                              # positional superko: no whole-board repetition
+            seen.add(key)
+        for p in players:
+            p.ack(move)
+        cur ^= 1
+    assert state.get_winner() in (go.BLACK, go.WHITE, 0)
+    assert players[0].mcts._eng.cfg.enforce_superko == 1
+    c = state.copy()
+    assert c.enforce_superko and np.array_equal(c.legal_mask(), state.legal_mask())

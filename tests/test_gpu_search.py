@@ -435,3 +435,53 @@ def test_batched_trajectory_pop_equals_single_pops():
         engs[0].trajectory_pop_many([1, 2], [pa[1] + 1, pa[2]])   # ply counts that do not match the device
     for e in engs:
         e.close()
+
+
+def test_search_under_positional_superko_against_oracle():
+    """enforce_superko inside the search (every playout state is a copy() that keeps previous_hashes, env/go.py:250-252, so
+    leaf legality respects superko): whole games on a 4x4 board, where captured points are replayed all the time, against
+    the oracle playing with the same rule (the oracle's superko is pinned to the reference by the rulesko_* fixtures)."""
+    from alphazero_amd.engine import Engine
+    H, P, db, mt, G = 4, 40, 4, 120, 6
+    rng = np.random.RandomState(9)
+    eng = Engine("go", H, H, n_slots=G, max_playout=P, transform_types=8, dirichlet_before=db, max_turn=mt, rng_replay=True,
+                 record_trajectories=True, enforce_superko=True)
+    O = eng.O
+    streams = []
+    for s in range(G):
+        st = (rng.randint(0, 8, size=(mt + 2) * (P + 1)).astype(np.int32), rng.gamma(0.03, 1.0, size=(mt + 2) * O), rng.rand(mt + 2))
+        streams.append(st)
+        eng.rng_inject(s, *st)
+    eng.selfplay_start()
+    _selfplay_injected(eng)
+    differs = 0
+    for s in range(G):
+        tr = eng.trajectory_pop(s)
+        for superko in (True, False):
+            cfg = oz.OzGameCfg(0, H, H, 0, 8, P, db, mt, 0.03, 0.25)
+            ref = _oracle_game_superko(cfg, streams[s], superko, mt + 2, O)
+            same = np.array_equal(tr["moves"], ref["moves"]) and np.array_equal(tr["visits"], ref["visits"]) and tr["winner"] == ref["winner"]
+            if superko:
+                assert same, s
+            else:
+                differs += not same
+    assert differs > 0        # the rule mattered in at least one of these games
+    eng.close()
+
+
+def _oracle_game_superko(cfg, stream, superko, max_plies, O):
+    """Game.start on the oracle with GameState(enforce_superko=superko): two trees, oz_tree_search per move."""
+    st = oz.State("go", cfg.H, cfg.W, enforce_superko=superko)
+    trees = [oz.Tree(O, cfg.transform_types, cfg.d_alpha, cfg.d_epsilon) for _ in range(2)]
+    rng = oz.Rng(*stream)
+    moves, visits, cur = [], [], 0
+    while not (st.s.is_end or st.s.turns > cfg.max_turn) and len(moves) < max_plies:
+        trees[cur].search(st, cfg.max_playout, st.s.turns <= cfg.dirichlet_before, oz.fn_ptr("oz_fake_eval"), rng)
+        a, n, w, p = trees[cur].root_stats()
+        row = np.zeros(O, np.int32); row[a] = n
+        mv = trees[cur].choose(float(stream[2][rng.r.i_unis])); rng.r.i_unis += 1
+        moves.append(mv); visits.append(row)
+        assert st.do_move(mv) == 0
+        trees[0].update_with_move(mv); trees[1].update_with_move(mv)
+        cur ^= 1
+    return dict(moves=np.array(moves, np.int16), visits=np.array(visits, np.int32).reshape(-1, O), winner=st.winner())
