@@ -178,6 +178,12 @@ __device__ __forceinline__ void glds16(const bf16_t *g, unsigned char *l)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
+// the same with the non-temporal cache policy (bytes read once: an activation slab)
+__device__ __forceinline__ void glds16_nt(const bf16_t *g, unsigned char *l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)l, 16, 0, 2);
+}
 
 template <bool RESID>
 __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
@@ -434,6 +440,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
     const int tile = xcd_tile(blockIdx.x, nwg);
 #ifdef STAMP
     int stamp_i = 0;
+    // wall-clock phases (100 MHz counter) of an early and a late workgroup: entry, K loop start, K loop end, exit
+    const int ph_slot = blockIdx.x == 300 ? 0 : (blockIdx.x == 3000 ? 4 : -1);
+#define PH_STAMP(k) do { if (ph_slot >= 0 && threadIdx.x == 0) g_stamps[1][500 + ph_slot + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    PH_STAMP(0);
+#else
+#define PH_STAMP(k) do {} while (0)
 #endif
     static_assert(V5_SLAB0 + 2 * SLAB_BYTES <= 147456, "slab buffers overflow LDS");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[V5_LDS_BYTES];
@@ -499,7 +511,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
 #endif
         unsigned char *dst = smem + V5_SLAB0 + (cc & 1) * SLAB_BYTES + wave * 1024;
 #pragma unroll
+#ifdef SLAB_NT
+        for (int i = 0; i < NSP; i++) glds16_nt(X + soff[i] + cc * 32, dst + i * 8192);
+#else
         for (int i = 0; i < NSP; i++) glds16(X + soff[i] + cc * 32, dst + i * 8192);
+#endif
     };
     auto rd_frags = [&](int cc, int tap) {
 #ifdef ABL_NOREAD
@@ -576,6 +592,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
     issue_slab(0); issue_w(0, 0); issue_w(0, 1); issue_w(0, 2);
     wait_vmcnt<2 * WB>();
     PP_BAR();
+    PH_STAMP(1);
 #ifdef STAMP
     if (blockIdx.x == 300 && threadIdx.x == 0) { g_stamps[0][500] = __builtin_amdgcn_s_memrealtime(); g_stamps[0][502] = __builtin_amdgcn_s_memtime(); }
 #endif
@@ -621,7 +638,150 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
 #endif
     // (a register-swap epilogue without the LDS round trip measured 1-3 % slower in the self-play bench)
     __syncthreads();
+    PH_STAMP(2);
     conv_epilogue<RESID, NI>(smem, rowoff, acc, bias, R, Y, M, m0, wave, lane, wr, cout0 + wc * CW);
+    PH_STAMP(3);
+#undef PH_STAMP
+}
+
+// ---------------------------------------------------------------------------
+// Two-workgroups-per-CU form of the slab kernel (19x19-class boards, NSP = 3).  A workgroup of 4 waves owns 256 points x
+// 128 output channels (blockIdx picks the channel half), needs 74 KB of LDS, and two of them share a compute unit: each
+// SIMD then holds one wave of either workgroup, and while one workgroup sits in its prologue (first DMA), at a barrier or
+// in its epilogue (transpose, residual, stores - 11 to 15 % of a tile's life in the one-workgroup kernel, where nothing
+// else is resident to cover it) the other one's wave keeps the matrix pipe busy.  No hand-made ping-pong: the two
+// workgroups are not synchronised with each other.  Per half-step (one tap x 32 input channels) a wave waits for its
+// share of the weights' LDS-DMA (counted vmcnt), passes ONE raw barrier, issues the DMA two half-steps ahead into the
+// ring slot that barrier has just freed, reads 4 + 8 fragments and issues 32 MFMAs.  The slab is shared by the two
+// channel halves of a tile only through L2 (both are placed on the same XCD, next to each other).
+// ---------------------------------------------------------------------------
+#define V6_RING 0
+#define V6_SLAB0 24576
+#define V6_TABLES 73728
+#define V6_LDS_BYTES (73728 + 2048)
+template <bool RESID>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_conv3x3_c256_bf16_duo(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt, const float *__restrict__ bias,
+                             const bf16_t *__restrict__ R, bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP, int npos,
+                             const int32_t *__restrict__ cnt)
+{
+    constexpr int CIN = 256, NCC = 8, NSP = 3, SLAB_BYTES = NSP * 128 * 64;
+    int nwg = gridDim.x;
+    if (cnt) {
+        const int nb = *cnt;
+        M = nb * HW; npos = nb * PP;
+        nwg = 2 * ((M + 255) >> 8);
+        if ((int)blockIdx.x >= nwg) return;
+    }
+    const int L = xcd_tile(blockIdx.x, nwg);
+    const int tile = L >> 1, cout0 = (L & 1) * 128;
+#ifdef STAMP
+    const int ph_slot = blockIdx.x == 600 ? 0 : (blockIdx.x == 6000 ? 4 : -1);
+#define PH_STAMP(k) do { if (ph_slot >= 0 && threadIdx.x == 0) g_stamps[1][500 + ph_slot + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    PH_STAMP(0);
+#else
+#define PH_STAMP(k) do {} while (0)
+#endif
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[V6_LDS_BYTES];
+    int *rowoff = reinterpret_cast<int *>(smem + V6_TABLES);
+    int *srow = reinterpret_cast<int *>(smem + V6_TABLES + 1024);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = tile * 256, W2 = Wd + 2;
+    {
+        int m = min(m0 + tid, M - 1);
+        int b = m / HW, pix = m - b * HW, y = pix / Wd, x = pix - y * Wd;
+        rowoff[tid] = b * PP + (y + 1) * W2 + (x + 1);
+    }
+    __syncthreads();
+    const int pbase = rowoff[0] - (W2 + 1);
+    srow[tid] = (rowoff[tid] - pbase) * 64;
+    const int frow = lane >> 2, fslot = lane & 3;
+    int woff[2];   // weights: wave w fills rows w*32 + q*16 + (lane >> 2) of the 128-row stage
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int r = wave * 32 + q * 16 + frow;
+        woff[q] = (cout0 + r) * 9 * CIN + ((fslot ^ (((r >> 2) & 1) << 1)) << 3);
+    }
+    int soff[6];   // slab: wave w fills the 16-row pieces w + 4*i
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const int sr = (wave + 4 * i) * 16 + frow;
+        const int pos = min(pbase + sr, npos - 1);
+        soff[i] = pos * CIN + ((fslot ^ (((sr >> 2) & 1) << 1)) << 3);
+    }
+    const int wrdo = (wc * 64 + (lane & 15)) * 64 + ((((lane >> 4)) ^ ((((lane & 15) >> 2) & 1) << 1)) << 4);
+    __syncthreads();
+    int xrow[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) xrow[j] = srow[wr * 128 + j * 16 + (lane & 15)] + ((lane >> 4) << 4);
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 wf[4], xf[8];
+    int opaque0 = 0;
+
+    auto issue_w = [&](int cc, int tap) {   // weights of half-step h = 9*cc + tap -> ring slot h % 3 = tap % 3
+        const int wofs = tap * CIN + cc * 32 + opaque0;
+        unsigned char *dst = smem + V6_RING + (tap % 3) * 8192 + wave * 2048;
+#pragma unroll
+        for (int q = 0; q < 2; q++) glds16(Wt + woff[q] + wofs, dst + q * 1024);
+    };
+    auto issue_slab = [&](int cc) {
+        unsigned char *dst = smem + V6_SLAB0 + (cc & 1) * SLAB_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 6; i++) glds16(X + soff[i] + cc * 32, dst + i * 4096);
+    };
+
+    issue_slab(0); issue_w(0, 0); issue_w(0, 1);
+    PH_STAMP(1);
+    for (int cc = 0; cc < NCC; cc++) {
+        asm volatile("" : "+s"(opaque0));
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            // this wave's share of W(h), h = 9*cc + tap, (and of the chunk's slab) has landed; younger loads may stay in flight: W(h+1), and
+            // the 6 slab pieces issued one or two half-steps ago
+            if (cc == NCC - 1 && tap == 8) wait_vmcnt<0>();
+            else if (cc < NCC - 1 && (tap == 1 || tap == 2)) wait_vmcnt<2 + 6>();
+            else wait_vmcnt<2>();
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");  // everybody's share has landed, and everybody is done reading half-step h-1
+            __builtin_amdgcn_sched_barrier(0);
+            {   // fragment reads first: their LDS latency runs while the DMA for two half-steps ahead is issued
+                const int ty = tap / 3, tx = tap - ty * 3;
+                const int tshift = ((ty - 1) * W2 + (tx - 1)) * 64 + opaque0;
+                const unsigned char *wb = smem + V6_RING + (tap % 3) * 8192 + wrdo;
+                const unsigned char *sb = smem + V6_SLAB0 + (cc & 1) * SLAB_BYTES;
+#pragma unroll
+                for (int i = 0; i < 4; i++) wf[i] = *reinterpret_cast<const bf16x8 *>(wb + i * 1024);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int a = xrow[j] + tshift;
+                    xf[j] = *reinterpret_cast<const bf16x8 *>(sb + (a ^ ((a & 256) >> 3)));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 2 < 9) issue_w(cc, tap + 2);
+            else if (cc < NCC - 1) issue_w(cc + 1, tap + 2 - 9);
+            if (tap == 0 && cc < NCC - 1) issue_slab(cc + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // point-block major: the first MFMAs need only the weights and the first point fragment
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[i]), "v"(xf[j]));
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __syncthreads();
+    PH_STAMP(2);
+    conv_epilogue<RESID, 4>(smem, rowoff, acc, bias, R, Y, M, m0, wave, lane, wr, cout0 + wc * 64);
+    PH_STAMP(3);
+#undef PH_STAMP
 }
 
 // largest number of padded positions (incl. the one-row-plus-one halo on both sides) that a tile of
@@ -662,6 +822,18 @@ static inline void launch_v5_cw(int cs, dim3 g, dim3 blk, hipStream_t st, const 
     if (cs == 4) hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<RESID, NSP, 256, 16>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
     else if (cs == 2) hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<RESID, NSP, 256, 32>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
     else hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<RESID, NSP, 256, 64>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+}
+
+// the two-workgroups-per-CU form: boards whose slab fits 3 x 128 positions, batches that fill the chip
+static inline bool launch_v6(const bf16_t *X, const bf16_t *Wt, const float *bias, const bf16_t *R, bf16_t *Y, int M, int HW, int Wd,
+                             int PP, hipStream_t st = 0, const int32_t *cnt = nullptr)
+{
+    if (conv_slab_span(HW, Wd, PP) > 3 * 128) return false;
+    const int npos = (M / HW) * PP;
+    dim3 g(2 * ((M + 255) / 256)), blk(256);
+    if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16_duo<true>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+    else hipLaunchKernelGGL((k_conv3x3_c256_bf16_duo<false>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+    return true;
 }
 
 // cs: channel split (1, 2 or 4), 0 = choose from the batch size

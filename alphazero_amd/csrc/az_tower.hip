@@ -50,6 +50,7 @@ struct Tower {
     struct Graph { const void *planes; const void *priors, *values, *rows; int B; hipStream_t st; hipGraphExec_t exec; };
     std::vector<Graph> graphs;
     bool use_graphs;
+    bool use_duo;   // two-workgroups-per-CU conv kernel where it applies (AZ_CONV_DUO=0 switches it off: A/B timing only)
 };
 
 static inline bf16_t h_f2bf(float f)
@@ -276,6 +277,7 @@ Tower *tower_create(int H, int W, int O, int num_blocks, int channels, int dtype
     t->dtype = dtype; t->maxB = max_batch; t->ready = false;
     t->profile = false; t->evs_used = 0; t->conv_ms = 0; t->conv_launches = 0;
     t->use_graphs = getenv("AZ_NO_GRAPHS") == nullptr;  // the variable only serves A/B timing
+    { const char *e = getenv("AZ_CONV_DUO"); t->use_duo = !(e && e[0] == '0'); }
     const size_t C = channels, HW = t->HW;
     t->blob_floats = C * 9 * 17 + C + (size_t)num_blocks * 2 * (C * 9 * C + C) + 3 * C + 3 + 2 * HW * O + O + HW * 256 + 256 + 256 + 1;
     const size_t es = dtype == 1 ? 2 : 4;
@@ -365,10 +367,13 @@ template <>
 void launch_conv<bf16_t>(const Tower *t, const bf16_t *X, const bf16_t *Wt, const float *bias, const bf16_t *R, bf16_t *Y, int B,
                          int cin, hipStream_t st, const int32_t *cnt)
 {
+    // batches that fill the chip with whole 256-point tiles, boards whose slab fits 3 x 128 positions (19x19): the form
+    // with two 4-wave workgroups per compute unit (each 256 points x 128 channels)
+    const bool duo = t->use_duo && cin == 256 && t->C == 256 && conv_channel_split(B * t->HW) == 1;
     if (cnt) {  // device-side batch size: only the slab kernels take it (tower_takes_device_count() said they apply)
         const int Mc = B * t->HW;
         if (cin == CIN0) launch_v5_stem(X, Wt, bias, Y, Mc, t->HW, t->W, t->PP, st, cnt);
-        else launch_v5(X, Wt, bias, R, Y, Mc, t->HW, t->W, t->PP, st, cnt);
+        else if (!(duo && launch_v6(X, Wt, bias, R, Y, Mc, t->HW, t->W, t->PP, st, cnt))) launch_v5(X, Wt, bias, R, Y, Mc, t->HW, t->W, t->PP, st, cnt);
         return;
     }
     const int M = B * t->HW;
@@ -380,6 +385,7 @@ void launch_conv<bf16_t>(const Tower *t, const bf16_t *X, const bf16_t *Wt, cons
         return;
     }
     if (cin == 256 && t->C == 256) {
+        if (duo && launch_v6(X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, st)) return;
         // slab kernel when a 256-pixel tile spans at most 512 padded positions (boards of 8x8 and larger)
         if (launch_v5(X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, st)) return;
         dim3 g2((M + 255) / 256), b2(512);

@@ -457,3 +457,45 @@ def test_play_cmd_shaped_game_on_the_device_tower():
     assert players[0].mcts._eng.cfg.enforce_superko == 1
     c = state.copy()
     assert c.enforce_superko and np.array_equal(c.legal_mask(), state.legal_mask())
+
+
+def test_device_trajectories_through_replay_files_and_ring(tmp_path):
+    """Games the device played, written the way DataPool stores them (one np.savez_compressed per game with keys
+    arr_0..2, datapool.py:65-66), read back the way it reloads them (datapool.py:54-58) and merged into the replay ring:
+    the arrays a reference optimizer would sample are the get_history() tuples the engine produced."""
+    import alphazero_amd.env.mnk as mnk
+    from alphazero_amd.data.replay import ReplayPool, load_games, save_game
+    from alphazero_amd.evaluator.nn_eval import NNEvaluator
+    from alphazero_amd.game.gameplay import BatchedSelfplay
+    cfg = _cfg("mnk", 3, 3, 9, 0, 3)
+    mnk.game_config.update(board_height=3, board_width=3, k=3)
+    ev = NNEvaluator(cfg, num_blocks=1, channels=128, dtype="bf16", max_batch_size=4, seed=5)
+    sp = BatchedSelfplay(ev, cfg, {"player": {"max_playout": 12}, "dirichlet_before": 30, "max_turn": 400}, n_games=12, seed=1)
+    hist = sp.run(12)
+    store = str(tmp_path / "pool")
+    pool = ReplayPool({"pool_size": 40, "start_data_size": 10, "store_path": store, "load_prev": False})
+    for h in hist:
+        pool.put(h)                                            # ring + '<count>.npz'
+    import os
+    files = sorted(os.listdir(store), key=lambda f: int(f.split(".")[0]))
+    assert files == ["%d.npz" % i for i in range(12)]
+    with np.load(os.path.join(store, "3.npz")) as z:
+        assert sorted(z.files) == ["arr_0", "arr_1", "arr_2"]
+        assert z["arr_0"].dtype == np.float64 and z["arr_0"].shape[1:] == (17, 3, 3) and z["arr_1"].shape[1] == 9
+        for k, a in enumerate(hist[3]):
+            assert np.array_equal(z["arr_%d" % k], a)
+    back = {a.tobytes() + b.tobytes() + c.tobytes() for a, b, c in load_games(store)}
+    assert back == {a.tobytes() + b.tobytes() + c.tobytes() for a, b, c in hist}
+    # the ring holds the rows in arrival order, wrapped at the capacity (datapool.py:87-112)
+    rows = np.concatenate([h[1] for h in hist])
+    n = len(rows)
+    assert pool.is_full == (n > 40) and pool.training_started
+    last = rows[-40:] if n >= 40 else rows
+    ring = np.roll(pool.data_pool[1], -pool.pool_end_index, axis=0) if n > 40 else pool.data_pool[1][:n]
+    assert np.array_equal(ring[-len(last):], last)
+    s_, p_, r_ = pool.get(16)
+    assert s_.shape == (16, 17, 3, 3) and np.allclose(p_.sum(axis=1), 1.0) and set(np.unique(r_)) <= {-1.0, 1.0}
+    # a fresh pool with load_prev picks the files up again (datapool.py:50-58)
+    pool2 = ReplayPool({"pool_size": 400, "start_data_size": 10, "store_path": store, "load_prev": True})
+    assert pool2.count == 12 and pool2.pool_end_index == n
+    mnk.game_config.update(board_height=6, board_width=5, k=4)

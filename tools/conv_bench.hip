@@ -41,12 +41,18 @@ int main(int argc, char **argv)
     std::vector<bf16_t> hX(act, 0), hR(act, 0), hW((size_t)C * 9 * C);
     std::vector<float> hb(C);
     srand(1);
+    const bool relu_data = getenv("RELU") != nullptr;
     auto rnd = []() { return (float)rand() / RAND_MAX * 2.f - 1.f; };
     for (int b = 0; b < B; b++)
         for (int y = 0; y < H; y++)
             for (int x = 0; x < Wd; x++) {
                 size_t o = ((size_t)b * PP + (y + 1) * (Wd + 2) + (x + 1)) * C;
-                if (b < 64 || check == 0) for (int c = 0; c < C; c++) { hX[o + c] = h_bf(rnd()); hR[o + c] = h_bf(rnd()); }
+                // RELU=1: operands like the tower's real ones (outputs of a ReLU: about half zeros, the rest positive)
+                if (b < 64 || check == 0) for (int c = 0; c < C; c++) {
+                    float a = rnd(), r = rnd();
+                    if (relu_data) { a = a > 0 ? a : 0.f; r = r > 0 ? r : 0.f; }
+                    hX[o + c] = h_bf(a); hR[o + c] = h_bf(r);
+                }
                 else { size_t src = ((size_t)(b % 64) * PP + (y + 1) * (Wd + 2) + (x + 1)) * C; memcpy(&hX[o], &hX[src], C * 2); memcpy(&hR[o], &hR[src], C * 2); }
             }
     for (auto &w : hW) w = h_bf(rnd() * 0.03f);
@@ -62,6 +68,9 @@ int main(int argc, char **argv)
         default:
             if (resid) hipLaunchKernelGGL((k_conv3x3_c256_bf16<true>), g, blk, 0, 0, X, Wt, bias, R, Y, M, HW, Wd, PP);
             else hipLaunchKernelGGL((k_conv3x3_c256_bf16<false>), g, blk, 0, 0, X, Wt, bias, (const bf16_t *)nullptr, Y, M, HW, Wd, PP);
+            break;
+        case 6:
+            if (!launch_v6(X, Wt, bias, resid ? R : nullptr, Y, M, HW, Wd, PP, 0, nullptr)) { printf("duo kernel not applicable\n"); exit(1); }
             break;
         case 5:
             if (!launch_v5(X, Wt, bias, resid ? R : nullptr, Y, M, HW, Wd, PP, 0, nullptr, cs)) { printf("slab kernel not applicable\n"); exit(1); }
@@ -116,6 +125,11 @@ int main(int argc, char **argv)
             double rt = (double)(st[0][501] - st[0][500]) * 10.0;  // 100 MHz ticks -> ns
             double cyc = (double)(st[0][503] - st[0][502]);
             printf("K loop of one workgroup: %.0f shader cycles in %.0f ns -> %.3f GHz, %.1f cycles per 32-MFMA interval\n", cyc, rt, cyc / rt, cyc / 145.0);
+            for (int w = 0; w < 2; w++) {
+                const unsigned long long *p = &st[1][500 + 4 * w];
+                printf("workgroup %s wall clock: prologue %.2f us, K loop %.2f us, epilogue (stores issued) %.2f us\n", w ? "late" : "early",
+                       (p[1] - p[0]) * 0.01, (p[2] - p[1]) * 0.01, (p[3] - p[2]) * 0.01);
+            }
         }
     }
 #endif
