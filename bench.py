@@ -30,7 +30,7 @@ MFMA_PEAK_TFLOPS_BF16 = 2500.0  # dense bf16 MFMA peak of one MI355X, TFLOP/s
 def measured_traffic(games, board, channels):
     """HBM bytes per launch of the dominant conv kernel from the committed PMC passes (they cannot be
     collected inside a timed run); None when the workload is not the one the counters were taken on."""
-    path = os.path.join(ROOT, "profiles", "round1_traffic.json")
+    path = os.path.join(ROOT, "profiles", "round2_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
@@ -237,7 +237,7 @@ def main():
                                             c["peak_tree_blocks"] / max(c["tree_block_cap"], 1))},
             "tree_stats_per_sim": {"levels": c["levels"] / max(c["evals"], 1), "children_scanned": c["children_scanned"] / max(c["evals"], 1)},
             "roofline": {
-                "bound": "mfma", "kernel": "k_conv3x3_c256_bf16_slab (3x3 256->256 implicit GEMM, bf16 MFMA 16x16x32)",
+                "bound": "mfma", "kernel": "k_conv3x3_c256_bf16_duo (3x3 256->256 implicit GEMM, bf16 MFMA 16x16x32, two 4-wave workgroups per CU)",
                 "achieved": achieved, "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_PEAK_TFLOPS_BF16, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": conv_ms, "launches": c["conv_launches"], "flops_per_launch": c["conv_flops_per_launch"],

@@ -27,31 +27,38 @@ def val(txt, pat):
 
 
 # kernel trace
-hdr = ("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline   (MI355X, 3993 games per GPU, "
-       "slab-reuse conv kernel with XCD-aware tile order; collected by profiles/collect.sh)\n")
+ROUND = "round2"
+hdr = ("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline   (MI355X, 3993 games per GPU, "
+       "41 rounds per step; the 3x3 256->256 convolutions run the two-workgroups-per-CU kernel k_conv3x3_c256_bf16_duo; collected by "
+       "profiles/collect.sh)\n")
 body = run(os.path.join(HERE, "rocpd_summary.py"), os.path.join(P, "trace", "trace_results.db"))
 bench = open(os.path.join(P, "trace_bench.json")).read().strip().splitlines()[-1]
-open(os.path.join(HERE, "round1_slab_kernel_stats.txt"), "w").write(hdr + body + "\n# bench line of the same run:\n" + bench + "\n")
+open(os.path.join(HERE, ROUND + "_kernel_stats.txt"), "w").write(hdr + body + "\n# bench line of the same run:\n" + bench + "\n")
 
 # HBM traffic
 f = run(os.path.join(HERE, "pmc_summary.py"), os.path.join(P, "pmc_fetch", "fetch_counter_collection.csv"))
 w = run(os.path.join(HERE, "pmc_summary.py"), os.path.join(P, "pmc_write", "write_counter_collection.csv"))
-fp, fr, ws = val(f, "slab<false, 3, 256"), val(f, "slab<true, 3, 256"), val(w, "slab<true, 3, 256")
+fp, fr, ws = val(f, "duo<false>"), val(f, "duo<true>"), val(w, "duo<true>")
 rd, wr = 2 * (fp + fr) / 2 * 1024 / 1e6, ws * 1024 / 1e6
-hdr2 = ("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline   "
+hdr2 = ("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline   "
         "(3993 games per GPU)\n# counter unit: KiB per dispatch (mean).  On gfx950 FETCH_SIZE counts 128-B read requests as 64 B: double it for bytes.\n")
 tail = """
 # conv 3x3 256->256, 3993 boards, per launch (mean of the plain and the residual variant, 20 launches each per tower pass):
 #   read  = 2 * (%.1f + %.1f)/2 KiB = %.1f MB ; write = %.1f KiB = %.1f MB (= 3993*361*256*2 B exactly) ; total %.1f MB
 #   algorithmic: activations in 901.6 MB (padded NHWC bf16) + weights 1.2 MB + out 738.0 MB (+738.0 MB residual read on every second launch) = 2009.8 MB mean
-#   read amplification %.2fx (plain) / %.2fx (residual): halo rows of neighbouring tiles that miss L2; with workgroup i -> tile i
-#   (neighbouring tiles on different XCDs) the harness measured 10.4 %% more read traffic (1040106 vs 932140 KiB at 4096 boards)
+#   read amplification %.2fx (plain) / %.2fx (residual): halo rows of neighbouring tiles, and the second channel half of a tile
+#   (its own workgroup, same XCD) re-reading the tile's activation slab when it has left L2
 """ % (fp, fr, rd, ws, wr, rd + wr, 2 * fp * 1024 / 1e6 / 902.8, 2 * fr * 1024 / 1e6 / (902.8 + 738.0))
-open(os.path.join(HERE, "round1_slab_pmc_traffic.txt"), "w").write(hdr2 + f + "\n" + w + tail)
-jp = os.path.join(HERE, "round1_traffic.json")
-j = json.load(open(jp))
+open(os.path.join(HERE, ROUND + "_pmc_traffic.txt"), "w").write(hdr2 + f + "\n" + w + tail)
+jp = os.path.join(HERE, ROUND + "_traffic.json")
+j = {"kernel": "k_conv3x3_c256_bf16_duo", "boards": 3993, "board": 19, "channels": 256, "fetch_correction": 2.0,
+     "unit_note": "counter values are KiB per dispatch",
+     "source": "profiles/%s_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE, separate passes; FETCH_SIZE doubled for gfx950)" % ROUND}
 j.update(fetch_size_kib_plain=fp, fetch_size_kib_resid=fr, write_size_kib=ws, traffic_bytes_per_launch=int(round((rd + wr) * 1e6)))
 json.dump(j, open(jp, "w"), indent=1)
+print("read %.1f MB write %.1f MB per launch" % (rd, wr))
+if mtag == "-":
+    sys.exit(0)
 
 # MFMA counters of the harness
 m = run(os.path.join(HERE, "pmc_summary.py"), os.path.join(PM, "pmc", "mfma_counter_collection.csv"))
@@ -77,5 +84,5 @@ tail3 = """
 # SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = %.0f %% (issue stalls: MFMA dependency / pipe), SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.0f %% (waitcnt + barrier)
 """ % (g / 1e6, cyc / 1e6, per_simd / 1e6, per_simd / 1e6, cyc / 1e6, 100 * util, ms, cyc / ms / 1e6, 100 * util * (cyc / ms / 1e6) / 2.4,
        runline, 100 * wi / wavec, 100 * wa / wavec)
-open(os.path.join(HERE, "round1_slab_pmc_mfma.txt"), "w").write(hdr3 + "\n".join(rows) + "\n" + tail3)
+open(os.path.join(HERE, ROUND + "_pmc_mfma.txt"), "w").write(hdr3 + "\n".join(rows) + "\n" + tail3)
 print("read %.1f MB write %.1f MB per launch; MFMA pipe %.1f %%, %.2f GHz" % (rd, wr, 100 * util, cyc / ms / 1e6))
