@@ -1328,9 +1328,10 @@ extern "C" int az_counters_get(az_engine *h, az_counters *out)
     out->conv_ms = 0; out->conv_launches = 0; out->conv_flops_per_launch = 0;
     if (h->tower) {
         unsigned long long n = 0;
-        tower_profile_read(h->tower, &out->conv_ms, &n, false);
+        double flops = 0;
+        tower_profile_read(h->tower, &out->conv_ms, &n, &flops, false);
         out->conv_launches = n;
-        out->conv_flops_per_launch = tower_conv_flops_per_launch(h->tower, h->D.G);
+        out->conv_flops_per_launch = n ? flops / (double)n : 0.0;
     }
     return AZ_OK;
 }
@@ -1345,7 +1346,7 @@ extern "C" int az_counters_reset(az_engine *h)
     h->tower_calls = h->tower_evals = h->steps = 0;
     HIPCHK(hipMemset(h->net_tot, 0, 2 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(h->D.peak, 0, sizeof(int32_t) * AZ_CTR_BUCKETS * 2));
-    if (h->tower) { double a; unsigned long long b; tower_profile_read(h->tower, &a, &b, true); }
+    if (h->tower) { double a, c; unsigned long long b; tower_profile_read(h->tower, &a, &b, &c, true); }
     return AZ_OK;
 }
 

@@ -26,4 +26,4 @@ double tower_conv_flops_per_launch(const Tower *t, int B);
 // per-launch HIP-event timing of the residual-tower 3x3 convolutions
 void tower_set_profile(Tower *t, bool on);
 void tower_collect_profile(Tower *t);
-void tower_profile_read(Tower *t, double *conv_ms, unsigned long long *launches, bool reset);
+void tower_profile_read(Tower *t, double *conv_ms, unsigned long long *launches, double *flops, bool reset);

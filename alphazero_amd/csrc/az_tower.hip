@@ -23,6 +23,10 @@
 #ifndef GRAPH_MAX_POINTS
 #define GRAPH_MAX_POINTS 46208    // forwards up to 128 boards of 19x19 are replayed as captured graphs
 #endif
+#ifndef GROUP_ROUNDS
+#define GROUP_ROUNDS 2  // rounds of convolution tiles per group of boards (see tower_group_boards)
+#endif
+#define MAX_GROUPS 64
 #ifndef DEVICE_COUNT_MIN_POINTS
 #define DEVICE_COUNT_MIN_POINTS 23104  // batches from here on may take their size from device memory
 #endif
@@ -51,6 +55,12 @@ struct Tower {
     std::vector<Graph> graphs;
     bool use_graphs;
     bool use_duo;   // two-workgroups-per-CU conv kernel where it applies (AZ_CONV_DUO=0 switches it off: A/B timing only)
+    // large batches go through the tower in groups of boards (see forward_t): group size in boards (0 = automatic,
+    // -1 = never), per-group device-side counts, boards of every profiled launch
+    int group_boards, cus;
+    int32_t *gcnt;
+    std::vector<int> ev_boards;
+    double conv_flops;
 };
 
 static inline bf16_t h_f2bf(float f)
@@ -278,6 +288,13 @@ Tower *tower_create(int H, int W, int O, int num_blocks, int channels, int dtype
     t->profile = false; t->evs_used = 0; t->conv_ms = 0; t->conv_launches = 0;
     t->use_graphs = getenv("AZ_NO_GRAPHS") == nullptr;  // the variable only serves A/B timing
     { const char *e = getenv("AZ_CONV_DUO"); t->use_duo = !(e && e[0] == '0'); }
+    { const char *e = getenv("AZ_TOWER_GROUP_BOARDS"); t->group_boards = e ? atoi(e) : 0; }  // tests and A/B timing
+    t->conv_flops = 0;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        t->cus = cus;
+    }
     const size_t C = channels, HW = t->HW;
     t->blob_floats = C * 9 * 17 + C + (size_t)num_blocks * 2 * (C * 9 * C + C) + 3 * C + 3 + 2 * HW * O + O + HW * 256 + 256 + 256 + 1;
     const size_t es = dtype == 1 ? 2 : 4;
@@ -294,6 +311,7 @@ Tower *tower_create(int H, int W, int O, int num_blocks, int channels, int dtype
     ok = ok && (t->X0 = talloc<char>(t, act * CIN0 * es));
     ok = ok && (t->X = talloc<char>(t, act * C * es)) && (t->T = talloc<char>(t, act * C * es)) && (t->Y = talloc<char>(t, act * C * es));
     ok = ok && (t->hp = talloc<float>(t, (size_t)max_batch * 2 * HW)) && (t->hv = talloc<float>(t, (size_t)max_batch * HW));
+    ok = ok && (t->gcnt = talloc<int32_t>(t, MAX_GROUPS));
     if (!ok) { err = "device allocation failed"; tower_destroy(t); return nullptr; }
     return t;
 }
@@ -414,23 +432,28 @@ void launch_conv<float>(const Tower *t, const float *X, const float *Wt, const f
         hipLaunchKernelGGL((k_conv3x3_f32<false>), grid, block, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C);
 }
 
+// One pass of `B` boards through all layers.  `alias`: the second convolution of a block writes its output over its
+// residual input (each output element depends on the residual at that element only and nobody else reads it), so two
+// activation buffers are live instead of three.
 template <typename T>
-static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float *values, hipStream_t st, const int32_t *rows,
-                     const int32_t *cnt)
+static int forward_pass(Tower *t, const int8_t *planes, int B, float *priors, float *values, hipStream_t st, const int32_t *rows,
+                        const int32_t *cnt, bool alias)
 {
     const size_t C = t->C;
-    T *X0 = (T *)t->X0, *X = (T *)t->X, *Tm = (T *)t->T, *Y = (T *)t->Y;
+    T *X0 = (T *)t->X0, *X = (T *)t->X, *Tm = (T *)t->T, *Y = alias ? X : (T *)t->Y;
+    float *hp = t->hp, *hv = t->hv;
     const int ysplit = B < 64 ? 8 : 1;  // few boards: several workgroups per board in the memory-bound kernels
     hipLaunchKernelGGL((k_planes_to_nhwc<T>), dim3(B, ysplit), dim3(256), 0, st, planes, X0, t->H, t->W, rows, cnt);
     launch_conv<T>(t, X0, (const T *)t->w_stem, t->b_stem, (const T *)nullptr, X, B, CIN0, st, cnt);
     for (int l = 0; l < t->NB; l++) {
         const T *w1 = (const T *)t->w_conv + (size_t)(2 * l) * C * 9 * C;
         const T *w2 = (const T *)t->w_conv + (size_t)(2 * l + 1) * C * 9 * C;
-        if (t->profile) hipEventRecord(t->evs[t->evs_used++], st);
+        const bool prof = t->profile && (size_t)t->evs_used + 4 <= t->evs.size();
+        if (prof) { t->ev_boards[t->evs_used / 2] = B; hipEventRecord(t->evs[t->evs_used++], st); }
         launch_conv<T>(t, X, w1, t->b_conv + (size_t)(2 * l) * C, (const T *)nullptr, Tm, B, (int)C, st, cnt);
-        if (t->profile) { hipEventRecord(t->evs[t->evs_used++], st); hipEventRecord(t->evs[t->evs_used++], st); }
+        if (prof) { hipEventRecord(t->evs[t->evs_used++], st); t->ev_boards[t->evs_used / 2] = B; hipEventRecord(t->evs[t->evs_used++], st); }
         launch_conv<T>(t, Tm, w2, t->b_conv + (size_t)(2 * l + 1) * C, X, Y, B, (int)C, st, cnt);
-        if (t->profile) hipEventRecord(t->evs[t->evs_used++], st);
+        if (prof) hipEventRecord(t->evs[t->evs_used++], st);
         T *tmp = X; X = Y; Y = tmp;
     }
     {
@@ -438,14 +461,59 @@ static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float
         int lpp = 64;
         while (chunks % lpp) lpp >>= 1;                     // largest power of two <= 64 dividing it
         if (chunks == lpp)
-            hipLaunchKernelGGL((k_head_conv<T, true>), dim3(B, ysplit), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, t->hp, t->hv, t->HW,
+            hipLaunchKernelGGL((k_head_conv<T, true>), dim3(B, ysplit), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, hp, hv, t->HW,
                                t->W, t->PP, (int)C, lpp, cnt);
         else
-            hipLaunchKernelGGL((k_head_conv<T, false>), dim3(B, ysplit), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, t->hp, t->hv, t->HW,
+            hipLaunchKernelGGL((k_head_conv<T, false>), dim3(B, ysplit), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, hp, hv, t->HW,
                                t->W, t->PP, (int)C, lpp, cnt);
     }
-    hipLaunchKernelGGL(k_head_fc, dim3((B + FCB - 1) / FCB), dim3(384), 0, st, t->hp, t->hv, t->w_pfc, t->b_pfc, t->w_v1, t->b_v1, t->w_v2,
+    hipLaunchKernelGGL(k_head_fc, dim3((B + FCB - 1) / FCB), dim3(384), 0, st, hp, hv, t->w_pfc, t->b_pfc, t->w_v1, t->b_v1, t->w_v2,
                        t->b_v2, priors, values, t->HW, t->O, B, rows, cnt);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Boards per group for a batch of B boards (0: the whole batch in one pass).  The 256-channel bf16 tower moves three
+// activation tensors per convolution (input, residual, output) and a batch of thousands of boards streams all of them
+// through HBM in every layer.  A group of boards small enough that its two live activation buffers stay in the 256 MB
+// memory-side cache goes through ALL layers before the next group starts, over the same two buffers: from the second
+// layer on the convolutions find their operands in that cache.  A group is at most GROUP_ROUNDS full rounds of 256-point
+// tiles on the chip's compute units (a tile more would cost a whole extra round: 363 boards of 19x19 on 256 units, 82 MB
+// per buffer), and the groups of a batch are sized evenly.
+static int tower_group_boards(const Tower *t, int B)
+{
+    if (t->group_boards < 0 || t->dtype != 1 || t->C != 256) return 0;
+    int g = t->group_boards;
+    if (g == 0) {
+        g = GROUP_ROUNDS * t->cus * 256 / t->HW;
+        if (B < 2 * g) return 0;   // too small to be worth splitting
+    }
+    if (g < 1 || B <= g) return 0;
+    int n = (B + g - 1) / g;
+    if (n > MAX_GROUPS) n = MAX_GROUPS;
+    return (B + n - 1) / n;
+}
+
+__global__ void k_group_counts(const int32_t *__restrict__ cnt, int32_t *__restrict__ gcnt, int g, int n)
+{
+    const int i = threadIdx.x;
+    if (i < n) gcnt[i] = min(max(*cnt - i * g, 0), g);
+}
+
+template <typename T>
+static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float *values, hipStream_t st, const int32_t *rows,
+                     const int32_t *cnt)
+{
+    const int g = tower_group_boards(t, B);
+    if (g == 0) return forward_pass<T>(t, planes, B, priors, values, st, rows, cnt, false);
+    const int n = (B + g - 1) / g;
+    if (cnt) hipLaunchKernelGGL(k_group_counts, dim3(1), dim3(MAX_GROUPS), 0, st, cnt, t->gcnt, g, n);
+    for (int i = 0; i < n; i++) {
+        const int b0 = i * g, nb = B - b0 < g ? B - b0 : g;
+        // with a row map the i-th group's boards are rows[b0 ...] of the caller's arrays, otherwise rows b0 ...
+        const int rc = forward_pass<T>(t, rows ? planes : planes + (size_t)b0 * 17 * t->HW, nb, rows ? priors : priors + (size_t)b0 * t->O,
+                                       rows ? values : values + b0, st, rows ? rows + b0 : nullptr, cnt ? t->gcnt + i : nullptr, true);
+        if (rc) return rc;
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -462,7 +530,7 @@ int tower_forward(Tower *t, const int8_t *planes_dev, int B, float *priors_dev, 
     if (B < 1 || B > t->maxB) { err = "batch exceeds the tower's activation buffers"; return -1; }
     if (count_dev && !tower_takes_device_count(t, B)) { err = "this tower shape needs the batch size on the host"; return -1; }
     if (t->profile) t->evs_used = 0;  // (a sampled forward's events wait for tower_collect_profile across later forwards)
-    const bool graphable = t->use_graphs && !t->profile && !count_dev && (size_t)B * t->HW <= GRAPH_MAX_POINTS;
+    const bool graphable = t->use_graphs && !t->profile && !count_dev && (size_t)B * t->HW <= GRAPH_MAX_POINTS && tower_group_boards(t, B) == 0;
     if (graphable) {
         for (auto &g : t->graphs)
             if (g.B == B && g.planes == planes_dev && g.priors == priors_dev && g.values == values_dev && g.rows == rows_dev && g.st == st) {
@@ -496,7 +564,10 @@ void tower_set_profile(Tower *t, bool on)
 {
     t->profile = on;
     if (on && t->evs.empty()) {
-        t->evs.resize((size_t)4 * t->NB);
+        const int g = tower_group_boards(t, t->maxB);
+        const int groups = g ? (t->maxB + g - 1) / g : 1;
+        t->evs.resize((size_t)4 * t->NB * groups);   // forwards of fewer, larger groups need fewer
+        t->ev_boards.assign(t->evs.size() / 2, 0);
         for (auto &e : t->evs) hipEventCreate(&e);
     }
 }
@@ -506,13 +577,15 @@ void tower_collect_profile(Tower *t)
 {
     for (int i = 0; i + 1 < t->evs_used; i += 2) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, t->evs[i], t->evs[i + 1]) == hipSuccess) { t->conv_ms += ms; t->conv_launches++; }
+        if (hipEventElapsedTime(&ms, t->evs[i], t->evs[i + 1]) == hipSuccess) {
+            t->conv_ms += ms; t->conv_launches++; t->conv_flops += tower_conv_flops_per_launch(t, t->ev_boards[i / 2]);
+        }
     }
     t->evs_used = 0;
 }
 
-void tower_profile_read(Tower *t, double *conv_ms, unsigned long long *launches, bool reset)
+void tower_profile_read(Tower *t, double *conv_ms, unsigned long long *launches, double *flops, bool reset)
 {
-    *conv_ms = t->conv_ms; *launches = t->conv_launches;
-    if (reset) { t->conv_ms = 0; t->conv_launches = 0; }
+    *conv_ms = t->conv_ms; *launches = t->conv_launches; *flops = t->conv_flops;
+    if (reset) { t->conv_ms = 0; t->conv_launches = 0; t->conv_flops = 0; }
 }

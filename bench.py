@@ -38,8 +38,10 @@ def measured_traffic(games, board, channels):
         return None, None
     if (d.get("board"), d.get("channels")) != (board, channels):
         return None, None
-    # per-launch traffic is proportional to the number of boards (activations in/out; the weights are 0.05 %)
-    return int(d["traffic_bytes_per_launch"] * games / d["boards"]), d["source"] + "; measured at %d boards, scaled to %d" % (d["boards"], games)
+    # per-launch traffic is proportional to the number of boards of the launch (activations in/out; the weights, 1.2 MB, are
+    # 0.6 % of a 363-board launch)
+    return (int(d["traffic_bytes_per_launch"] * games / d["boards"]),
+            d["source"] + "; measured at %.0f boards per launch, scaled to %.0f" % (d["boards"], games))
 
 
 def cpu_baseline(game, H, k, num_blocks, channels, sims, budget_s=12.0):
@@ -206,7 +208,9 @@ def main():
     if rank == 0:
         conv_ms = c["conv_ms"] / max(c["conv_launches"], 1)
         achieved = c["conv_flops_per_launch"] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        traffic, traffic_src = measured_traffic(args.games, H, args.channels) if args.dtype == "bf16" else (None, None)
+        # the tower takes a large batch through its layers in groups of boards: a launch covers one group
+        boards_per_launch = c["conv_flops_per_launch"] / (2.0 * H * H * 9.0 * args.channels * args.channels)
+        traffic, traffic_src = measured_traffic(boards_per_launch, H, args.channels) if args.dtype == "bf16" and boards_per_launch > 0 else (None, None)
         out = {
             "metric": "self-play moves/sec + MCTS sims/sec (node), Go 19x19 800 sims, 1/2/4/8 GPUs",
             "value": moves_per_s, "unit": "moves/s", "sims_per_sec": sims_per_s,
@@ -241,8 +245,9 @@ def main():
                 "achieved": achieved, "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_PEAK_TFLOPS_BF16, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": conv_ms, "launches": c["conv_launches"], "flops_per_launch": c["conv_flops_per_launch"],
+                "boards_per_launch": boards_per_launch,
                 "timing": "HIP events on the launch stream around every conv launch of every %d-th round of the timed "
-                          "region (full batch in those rounds)" % max(8, args.profile_every),
+                          "region (all games evaluated in those rounds); flops_per_launch is the mean over the timed launches" % max(8, args.profile_every),
             },
             # HBM-side kernels: algorithmic bytes from the engine's counters / kernel time (HIP events around each phase)
             "hbm_kernels": hbm_kernels(c, H * H, O, rounds),

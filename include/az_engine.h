@@ -112,7 +112,7 @@ typedef struct az_counters {
     uint64_t tower_evals;      /* rows pushed through the tower */
     double conv_ms;            /* HIP-event time of the residual-tower 3x3 conv launches (az_tower_profile on) */
     uint64_t conv_launches;
-    double conv_flops_per_launch; /* 2 * n_slots * H*W * 9 * C^2 */
+    double conv_flops_per_launch; /* mean over the timed launches of 2 * boards in the launch * H*W * 9 * C^2 */
     uint64_t expansions_skipped;  /* tree_full_policy 1: expansions dropped because an arena was full */
     uint64_t peak_tree_edges;     /* most edges / expanded nodes any one tree has held since the last reset ... */
     uint64_t peak_tree_blocks;

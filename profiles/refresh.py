@@ -29,34 +29,45 @@ def val(txt, pat):
 # kernel trace
 ROUND = "round2"
 hdr = ("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline   (MI355X, 3993 games per GPU, "
-       "41 rounds per step; the 3x3 256->256 convolutions run the two-workgroups-per-CU kernel k_conv3x3_c256_bf16_duo; collected by "
+       "41 rounds per step; the 3x3 256->256 convolutions run the two-workgroups-per-CU kernel k_conv3x3_c256_bf16_duo, one launch per layer and "
+       "group of 363 boards; collected by "
        "profiles/collect.sh)\n")
 body = run(os.path.join(HERE, "rocpd_summary.py"), os.path.join(P, "trace", "trace_results.db"))
 bench = open(os.path.join(P, "trace_bench.json")).read().strip().splitlines()[-1]
 open(os.path.join(HERE, ROUND + "_kernel_stats.txt"), "w").write(hdr + body + "\n# bench line of the same run:\n" + bench + "\n")
 
-# HBM traffic
+# HBM traffic.  The tower takes the batch through its layers in groups of boards, so a launch covers one group; the number of
+# boards per launch comes from the bench line of the same run.
+if not os.path.exists(os.path.join(P, "pmc_write", "write_counter_collection.csv")):
+    print("no counter passes under", P, "- traffic summary left as it is")
+    sys.exit(0)
+bl = json.loads(bench)
+boards = bl["roofline"]["boards_per_launch"]
 f = run(os.path.join(HERE, "pmc_summary.py"), os.path.join(P, "pmc_fetch", "fetch_counter_collection.csv"))
 w = run(os.path.join(HERE, "pmc_summary.py"), os.path.join(P, "pmc_write", "write_counter_collection.csv"))
 fp, fr, ws = val(f, "duo<false>"), val(f, "duo<true>"), val(w, "duo<true>")
 rd, wr = 2 * (fp + fr) / 2 * 1024 / 1e6, ws * 1024 / 1e6
+a_in, a_out = boards * 441 * 512 / 1e6, boards * 361 * 512 / 1e6
 hdr2 = ("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline   "
-        "(3993 games per GPU)\n# counter unit: KiB per dispatch (mean).  On gfx950 FETCH_SIZE counts 128-B read requests as 64 B: double it for bytes.\n")
+        "(3993 games per GPU, the tower in groups of %.0f boards)\n# counter unit: KiB per dispatch (mean).  On gfx950 FETCH_SIZE counts 128-B "
+        "read requests as 64 B: double it for bytes.\n# The counters sit between L2 and the fabric: they count what leaves the XCDs' L2s, "
+        "whether the 256 MB memory-side cache or HBM itself serves it.\n" % boards)
 tail = """
-# conv 3x3 256->256, 3993 boards, per launch (mean of the plain and the residual variant, 20 launches each per tower pass):
-#   read  = 2 * (%.1f + %.1f)/2 KiB = %.1f MB ; write = %.1f KiB = %.1f MB (= 3993*361*256*2 B exactly) ; total %.1f MB
-#   algorithmic: activations in 901.6 MB (padded NHWC bf16) + weights 1.2 MB + out 738.0 MB (+738.0 MB residual read on every second launch) = 2009.8 MB mean
+# conv 3x3 256->256, %.0f boards per launch (mean of the plain and the residual variant, 20 launches each per group and tower pass):
+#   read  = 2 * (%.1f + %.1f)/2 KiB = %.1f MB ; write = %.1f KiB = %.1f MB ; total %.1f MB
+#   algorithmic: activations in %.1f MB (padded NHWC bf16) + weights 1.2 MB + out %.1f MB (+%.1f MB residual read on every second launch) = %.1f MB mean
 #   read amplification %.2fx (plain) / %.2fx (residual): halo rows of neighbouring tiles, and the second channel half of a tile
 #   (its own workgroup, same XCD) re-reading the tile's activation slab when it has left L2
-""" % (fp, fr, rd, ws, wr, rd + wr, 2 * fp * 1024 / 1e6 / 902.8, 2 * fr * 1024 / 1e6 / (902.8 + 738.0))
+""" % (boards, fp, fr, rd, ws, wr, rd + wr, a_in, a_out, a_out, a_in + 1.2 + 1.5 * a_out, 2 * fp * 1024 / 1e6 / (a_in + 1.2),
+       2 * fr * 1024 / 1e6 / (a_in + 1.2 + a_out))
 open(os.path.join(HERE, ROUND + "_pmc_traffic.txt"), "w").write(hdr2 + f + "\n" + w + tail)
 jp = os.path.join(HERE, ROUND + "_traffic.json")
-j = {"kernel": "k_conv3x3_c256_bf16_duo", "boards": 3993, "board": 19, "channels": 256, "fetch_correction": 2.0,
+j = {"kernel": "k_conv3x3_c256_bf16_duo", "boards": boards, "board": 19, "channels": 256, "fetch_correction": 2.0,
      "unit_note": "counter values are KiB per dispatch",
      "source": "profiles/%s_pmc_traffic.txt (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE, separate passes; FETCH_SIZE doubled for gfx950)" % ROUND}
 j.update(fetch_size_kib_plain=fp, fetch_size_kib_resid=fr, write_size_kib=ws, traffic_bytes_per_launch=int(round((rd + wr) * 1e6)))
 json.dump(j, open(jp, "w"), indent=1)
-print("read %.1f MB write %.1f MB per launch" % (rd, wr))
+print("%.0f boards per launch: read %.1f MB write %.1f MB" % (boards, rd, wr))
 if mtag == "-":
     sys.exit(0)
 

@@ -120,6 +120,64 @@ def test_device_count_and_row_list_path_matches_fp32_reference():
     eng.close()
 
 
+# Large batches go through the tower in groups of boards, each group through all layers over the same two activation
+# buffers (the second convolution of a block writes over its residual input).  AZ_TOWER_GROUP_BOARDS forces a group size
+# (read when the engine is created; -1 = the whole batch per layer).
+@pytest.mark.parametrize("game,H,B,group", [
+    ("go", 19, 150, 40),     # 4 groups of 38 boards: the tile kernels on every group
+    ("go", 19, 800, 0),      # automatic: 3 groups of 267 boards on 256 compute units
+    ("go", 9, 700, 130),     # 6 groups, slab of 4 x 128 positions
+    ("reversi", 8, 64, 7),   # 10 groups of 7 boards, the last one of 1: the kernels for few boards
+])
+def test_tower_in_board_groups_matches_the_whole_batch(monkeypatch, game, H, B, group):
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.network.model import fold_to_blob, random_net
+    O = H * H + (0 if game == "mnk" else 1)
+    NB = 2
+    net = random_net(H, H, O, NB, 256, seed=H + B, perturb_bn=True)
+    x = _boards(B, H, H, seed=B + 1)
+    out = {}
+    for g in (-1, group):
+        monkeypatch.setenv("AZ_TOWER_GROUP_BOARDS", str(g))
+        eng = Engine(game, H, H, 5, n_slots=B, num_blocks=NB, channels=256, tower_dtype="bf16")
+        eng.tower_load(fold_to_blob(net))
+        out[g] = eng.tower_forward(x)
+        eng.close()
+    p, v = out[group]
+    # the same arithmetic per board whichever group it is in; kernels chosen by batch size may order their sums differently
+    assert np.abs(p - out[-1][0]).max() <= 2e-3 and np.abs(v - out[-1][1]).max() <= 2e-3
+    pick = np.unique(np.array([0, 1, B // 3, B // 3 + 1, B // 2, 2 * B // 3, B - 2, B - 1]))
+    _assert_close(p[pick], v[pick], net, NB, x[pick], TOL["bf16"])
+    assert np.allclose(p.sum(axis=1), 1.0, atol=1e-4)
+
+
+def test_board_groups_with_device_count_and_row_list(monkeypatch):
+    """Leaf compaction (rows and their number in device memory) with the tower in groups of 100 boards: 330 of 600 slots
+    search, so three groups are full, one holds 30 boards and two are empty."""
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.network.model import fold_to_blob, random_net
+    monkeypatch.setenv("AZ_TOWER_GROUP_BOARDS", "100")
+    H, G, NB, S = 9, 600, 1, 330
+    rng = np.random.RandomState(6)
+    net = random_net(H, H, H * H + 1, NB, 256, seed=12, perturb_bn=True)
+    eng = Engine("go", H, H, n_slots=G, max_playout=4, transform_types=8, num_blocks=NB, channels=256, tower_dtype="bf16", seed=4)
+    eng.tower_load(fold_to_blob(net))
+    slots = np.sort(rng.choice(G, S, replace=False)).astype(np.int32)
+    for _ in range(6):
+        mask = eng.legal_mask(slots)[:, :H * H]
+        status, _ = eng.do_move(slots, [int(rng.choice(np.flatnonzero(m))) for m in mask])
+        assert np.all(status == 0)
+    eng.search_begin(slots, np.zeros(S, np.int32), np.zeros(S, np.int32))
+    assert eng.step_select() == S
+    planes, valid = eng.leaf_batch()
+    eng.step_finish()
+    p, v = eng.leaf_outputs()
+    pick = slots[[0, 1, 99, 100, 101, 199, 200, 299, 300, 301, S - 2, S - 1]]
+    _assert_close(p[pick], v[pick], net, NB, planes[pick], TOL["bf16"])
+    assert np.allclose(p[slots].sum(axis=1), 1.0, atol=1e-4)
+    eng.close()
+
+
 def _deep_net(H, O, NB, seed):
     """Random weights with the batch-norm statistics of every layer set from a batch of positions (then an offset
     beta), as a trained network's moving averages are.  With untouched statistics a random 20-block tower has

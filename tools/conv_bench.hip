@@ -145,6 +145,30 @@ int main(int argc, char **argv)
     ms /= iters;
     double fl = 2.0 * M * 9.0 * C * C;
     printf("variant %d resid %d B %d: %.4f ms  %.1f TFLOP/s  (%.1f%% of 2500)\n", variant, resid, B, ms, fl / ms / 1e9, fl / ms / 1e9 / 25.0);
+    if (getenv("CHUNK") && variant == 6) {
+        // the same work launched as chunks of CHUNK boards: over the whole buffers (every chunk touches new memory) and over the
+        // first chunk's memory again and again (activations stay in the memory-side cache if they fit)
+        const int cb = atoi(getenv("CHUNK")), nch = B / cb;
+        const size_t coff = (size_t)cb * PP * C;
+        for (int same = 0; same < 2; same++) {
+            auto pass = [&]() {
+                for (int c = 0; c < nch; c++) {
+                    size_t o = same ? 0 : c * coff;
+                    launch_v6(X + o, Wt, bias, resid ? R + o : nullptr, Y + o, cb * HW, HW, Wd, PP, 0, nullptr);
+                }
+            };
+            pass();
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < iters; i++) pass();
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            ms /= iters;
+            double flc = 2.0 * nch * cb * HW * 9.0 * C * C;
+            printf("chunks of %d boards (%d launches, %.0f MB per buffer), %s memory: %.4f ms  %.1f TFLOP/s\n", cb, nch, coff * 2 / 1e6,
+                   same ? "same" : "distinct", ms, flc / ms / 1e9);
+        }
+    }
     if (getenv("TWO") && variant == 5 && B % 2 == 0) {
         // the same work as two dependent chains of half-batch launches on two streams
         hipStream_t s2[2];
