@@ -476,9 +476,9 @@ static int forward_pass(Tower *t, const int8_t *planes, int B, float *priors, fl
 // activation tensors per convolution (input, residual, output) and a batch of thousands of boards streams all of them
 // through HBM in every layer.  A group of boards small enough that its two live activation buffers stay in the 256 MB
 // memory-side cache goes through ALL layers before the next group starts, over the same two buffers: from the second
-// layer on the convolutions find their operands in that cache.  A group is at most GROUP_ROUNDS full rounds of 256-point
+// layer on the convolutions find their operands in that cache.  A group is what fills GROUP_ROUNDS whole rounds of 256-point
 // tiles on the chip's compute units (a tile more would cost a whole extra round: 363 boards of 19x19 on 256 units, 82 MB
-// per buffer), and the groups of a batch are sized evenly.
+// per buffer); the last group of a batch takes what is left.
 static int tower_group_boards(const Tower *t, int B)
 {
     if (t->group_boards < 0 || t->dtype != 1 || t->C != 256) return 0;
@@ -488,9 +488,8 @@ static int tower_group_boards(const Tower *t, int B)
         if (B < 2 * g) return 0;   // too small to be worth splitting
     }
     if (g < 1 || B <= g) return 0;
-    int n = (B + g - 1) / g;
-    if (n > MAX_GROUPS) n = MAX_GROUPS;
-    return (B + n - 1) / n;
+    if ((B + g - 1) / g > MAX_GROUPS) g = (B + MAX_GROUPS - 1) / MAX_GROUPS;
+    return g;
 }
 
 __global__ void k_group_counts(const int32_t *__restrict__ cnt, int32_t *__restrict__ gcnt, int g, int n)

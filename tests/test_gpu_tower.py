@@ -124,9 +124,9 @@ def test_device_count_and_row_list_path_matches_fp32_reference():
 # buffers (the second convolution of a block writes over its residual input).  AZ_TOWER_GROUP_BOARDS forces a group size
 # (read when the engine is created; -1 = the whole batch per layer).
 @pytest.mark.parametrize("game,H,B,group", [
-    ("go", 19, 150, 40),     # 4 groups of 38 boards: the tile kernels on every group
-    ("go", 19, 800, 0),      # automatic: 3 groups of 267 boards on 256 compute units
-    ("go", 9, 700, 130),     # 6 groups, slab of 4 x 128 positions
+    ("go", 19, 150, 40),     # groups of 40, 40, 40 and 30 boards: the tile kernels on every group
+    ("go", 19, 800, 0),      # automatic: groups of 363, 363 and 74 boards on 256 compute units
+    ("go", 9, 700, 130),     # 5 groups of 130 boards and one of 50, slab of 4 x 128 positions
     ("reversi", 8, 64, 7),   # 10 groups of 7 boards, the last one of 1: the kernels for few boards
 ])
 def test_tower_in_board_groups_matches_the_whole_batch(monkeypatch, game, H, B, group):
@@ -144,8 +144,10 @@ def test_tower_in_board_groups_matches_the_whole_batch(monkeypatch, game, H, B, 
         out[g] = eng.tower_forward(x)
         eng.close()
     p, v = out[group]
-    # the same arithmetic per board whichever group it is in; kernels chosen by batch size may order their sums differently
-    assert np.abs(p - out[-1][0]).max() <= 2e-3 and np.abs(v - out[-1][1]).max() <= 2e-3
+    # the same arithmetic per board whichever group it is in (groups that run the same kernels as the whole batch are
+    # bit-identical); a smaller last group may get kernels that order their fp32 sums differently, which flips bf16
+    # roundings of some activations: half the bf16 tolerance is allowed for that
+    assert np.abs(p - out[-1][0]).max() <= 5e-3 and np.abs(v - out[-1][1]).max() <= 5e-3
     pick = np.unique(np.array([0, 1, B // 3, B // 3 + 1, B // 2, 2 * B // 3, B - 2, B - 1]))
     _assert_close(p[pick], v[pick], net, NB, x[pick], TOL["bf16"])
     assert np.allclose(p.sum(axis=1), 1.0, atol=1e-4)

@@ -14,7 +14,7 @@ for ln in sys.stdin:
 " >> $out || exit 1
   done
 }
-run --game go --board 9 --sims 400 --blocks 10 --games 4096
-run --game mnk --board 15 --k 5 --sims 800 --blocks 10 --games 2048
-run --game reversi --board 8 --sims 400 --blocks 6 --games 8192
+run --game go --board 9 --sims 400 --blocks 10 --games ${GO9:-4045}
+run --game mnk --board 15 --k 5 --sims 800 --blocks 10 --games ${GOMOKU:-4074}
+run --game reversi --board 8 --sims 400 --blocks 6 --games ${REVERSI:-4096}
 cat $out
