@@ -34,10 +34,17 @@ def game_config_to_engine_kwargs(game_config):
 def slots_for_whole_tile_rounds(n_max, board_height, board_width, compute_units=256, tile_points=256):
     """Largest slot count <= n_max whose board points fill a whole number of rounds of the tower's conv tiles
     (256 points each, one tile per compute unit at a time): a partly filled last round costs as much as a full one
-    in every conv launch (4096 slots of 15x15 are 14.06 rounds, 4077 are 14).  n_max itself when it is below one round."""
+    in every conv launch (4096 slots of 15x15 are 14.06 rounds).  The tower takes batches of four rounds and more in
+    groups of boards that fill two rounds each, whole boards per group (582 boards of 15x15; 4074 slots are 7 such groups),
+    and what is left over last.  n_max itself when it is below one round."""
     hw = board_height * board_width
-    rounds = (n_max * hw) // (tile_points * compute_units)
-    return (rounds * tile_points * compute_units) // hw if rounds >= 1 else n_max
+    per_round = tile_points * compute_units
+    rounds = (n_max * hw) // per_round
+    if rounds < 1:
+        return n_max
+    if rounds < 4:
+        return (rounds * per_round) // hw
+    return (rounds // 2) * ((2 * per_round) // hw) + (rounds % 2) * (per_round // hw)
 
 
 class Engine:

