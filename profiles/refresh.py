@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rewrites the committed summaries from the raw outputs of profiles/collect.sh <tag> and profiles/collect_mfma.sh <tag2>
 (gpurun_out/prof_<tag>, gpurun_out/prof_<tag2>).
-    python profiles/refresh.py final mfma_final"""
+    python profiles/refresh.py final mfma_final [tag of profiles/collect_pmc_short.sh]"""
 import csv
 import json
 import os
@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.join(HERE, "..")
 tag, mtag = sys.argv[1], sys.argv[2]
 P = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+PC = os.path.join(ROOT, "gpurun_out", "prof_" + (sys.argv[3] if len(sys.argv) > 3 else tag))   # counter passes (collect_pmc_short.sh)
 PM = os.path.join(ROOT, "gpurun_out", "prof_" + mtag)
 
 
@@ -38,18 +39,19 @@ open(os.path.join(HERE, ROUND + "_kernel_stats.txt"), "w").write(hdr + body + "\
 
 # HBM traffic.  The tower takes the batch through its layers in groups of boards, so a launch covers one group; the number of
 # boards per launch comes from the bench line of the same run.
-if not os.path.exists(os.path.join(P, "pmc_write", "write_counter_collection.csv")):
-    print("no counter passes under", P, "- traffic summary left as it is")
+if not os.path.exists(os.path.join(PC, "pmc_write", "write_counter_collection.csv")):
+    print("no counter passes under", PC, "- traffic summary left as it is")
     sys.exit(0)
 bl = json.loads(bench)
 boards = bl["roofline"]["boards_per_launch"]
-f = run(os.path.join(HERE, "pmc_summary.py"), os.path.join(P, "pmc_fetch", "fetch_counter_collection.csv"))
-w = run(os.path.join(HERE, "pmc_summary.py"), os.path.join(P, "pmc_write", "write_counter_collection.csv"))
+f = run(os.path.join(HERE, "pmc_summary.py"), os.path.join(PC, "pmc_fetch", "fetch_counter_collection.csv"))
+w = run(os.path.join(HERE, "pmc_summary.py"), os.path.join(PC, "pmc_write", "write_counter_collection.csv"))
 fp, fr, ws = val(f, "duo<false>"), val(f, "duo<true>"), val(w, "duo<true>")
 rd, wr = 2 * (fp + fr) / 2 * 1024 / 1e6, ws * 1024 / 1e6
 a_in, a_out = boards * 441 * 512 / 1e6, boards * 361 * 512 / 1e6
-hdr2 = ("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline   "
-        "(3993 games per GPU, the tower in groups of %.0f boards)\n# counter unit: KiB per dispatch (mean).  On gfx950 FETCH_SIZE counts 128-B "
+hdr2 = ("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 0 --rounds-per-step 2 --no-cpu-baseline   "
+        "(profiles/collect_pmc_short.sh: the counter passes abort inside the profiler on longer runs of this many dispatches; "
+        "3993 games per GPU, the tower in groups of %.0f boards)\n# counter unit: KiB per dispatch (mean).  On gfx950 FETCH_SIZE counts 128-B "
         "read requests as 64 B: double it for bytes.\n# The counters sit between L2 and the fabric: they count what leaves the XCDs' L2s, "
         "whether the 256 MB memory-side cache or HBM itself serves it.\n" % boards)
 tail = """
