@@ -40,6 +40,10 @@ struct az_engine {
     az_config cfg;
     Dev D;
     hipStream_t stream = nullptr;
+    // two-network matches: the second network's tower runs beside the first on a stream of its own (a match's half
+    // batches rarely fill the chip); created on first use
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<void *> allocs;
     std::string error;
     Tower *tower = nullptr;
@@ -65,6 +69,7 @@ struct az_engine {
     hipEvent_t ev[AZ_EVQ][4];
     int ev_head = 0, ev_pending = 0;
     bool conv_profile = false;      // per-launch conv timing on every round (host waits for each round)
+    bool serial_towers = getenv("AZ_MATCH_SERIAL_TOWERS") != nullptr;  // A/B timing: both towers of a match on one stream
     int prof_every = 0;             // > 0: per-launch conv timing on every prof_every-th round only, rounds stay queued
     bool ev_prof[AZ_EVQ] = {};      // the queued round of this event quad carries the tower's per-launch events
     uint64_t round_index = 0;
@@ -192,6 +197,9 @@ extern "C" void az_engine_destroy(az_engine *h)
     if (h->pop_visits) hipFree(h->pop_visits);
     for (int q = 0; q < AZ_EVQ; q++)
         for (int i = 0; i < 4; i++) if (h->ev[q][i]) hipEventDestroy(h->ev[q][i]);
+    if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -630,15 +638,33 @@ static int evaluate(az_engine *h, const void *priors, const void *values, int f6
                            h->net_tot);
         Tower *tw[2] = {h->tower, h->tower2};
         if (two_nets_async(h)) {
-            // the towers read their batch sizes from device memory: nothing comes back to the host, rounds can be queued
+            // the towers read their batch sizes from device memory: nothing comes back to the host, rounds can be queued.
+            // The two passes touch disjoint rows of priors / values and each tower has its own activations: the second
+            // runs on its own stream between a fork and a join event, so that two half-empty passes share the chip.
+            if (!h->stream2 && !h->serial_towers) {
+                // (a stream of another priority gets a hardware queue of its own; streams of one priority may share one,
+                // and kernels in one queue run one after the other)
+                int lo = 0, hi = 0;
+                if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void)hipGetLastError(); }
+                if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi) != hipSuccess ||
+                    hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (h->stream2) { hipStreamDestroy(h->stream2); h->stream2 = nullptr; }
+                    h->serial_towers = true;
+                }
+            }
+            const bool beside = h->stream2 && !h->serial_towers;
+            if (beside) { HIPCHK(hipEventRecord(h->ev_fork, h->stream)); HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0)); }
             for (int net = 0; net < 2; net++) {
-                if (tower_forward(tw[net], h->D.planes, G, (float *)h->D.priors, (float *)h->D.values, h->stream, terr,
-                                  h->net_rows + (size_t)net * G, h->net_cnt + net) != 0) {
+                if (tower_forward(tw[net], h->D.planes, G, (float *)h->D.priors, (float *)h->D.values, net && beside ? h->stream2 : h->stream,
+                                  terr, h->net_rows + (size_t)net * G, h->net_cnt + net) != 0) {
                     h->error = "tower: " + terr;
                     return AZ_ERR_HIP;
                 }
                 h->tower_calls++;
             }
+            if (beside) { HIPCHK(hipEventRecord(h->ev_join, h->stream2)); HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0)); }
             return AZ_OK;
         }
         int32_t cnt[2] = {0, 0};
