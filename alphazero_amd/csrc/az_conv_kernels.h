@@ -645,8 +645,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
 }
 
 // ---------------------------------------------------------------------------
-// Two-workgroups-per-CU form of the slab kernel (19x19-class boards, NSP = 3).  A workgroup of 4 waves owns 256 points x
-// 128 output channels (blockIdx picks the channel half), needs 74 KB of LDS, and two of them share a compute unit: each
+// Two-workgroups-per-CU form of the slab kernel.  A workgroup of 4 waves owns 256 points x 128 output channels (blockIdx
+// picks the channel half), needs 74 KB of LDS (slab of 24 pieces of 16 positions: 19x19 boards) or exactly 80 KB (27
+// pieces = 432 positions: 15x15, 9x9, 8x8 boards, whose tiles span up to 426), and two of them share a compute unit: each
 // SIMD then holds one wave of either workgroup, and while one workgroup sits in its prologue (first DMA), at a barrier or
 // in its epilogue (transpose, residual, stores - 11 to 15 % of a tile's life in the one-workgroup kernel, where nothing
 // else is resident to cover it) the other one's wave keeps the matrix pipe busy.  No hand-made ping-pong: the two
@@ -657,15 +658,18 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
 // ---------------------------------------------------------------------------
 #define V6_RING 0
 #define V6_SLAB0 24576
-#define V6_TABLES 73728
-#define V6_LDS_BYTES (73728 + 2048)
-template <bool RESID>
+// NPW = slab pieces (16 positions x 64 B) each wave fetches per channel chunk: 6 (24 pieces) or 7 (27 distinct pieces; the
+// 28th load repeats the 27th, so that every wave issues the same number of loads and the vmcnt bookkeeping stays uniform)
+template <bool RESID, int NPW = 6>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_conv3x3_c256_bf16_duo(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt, const float *__restrict__ bias,
                              const bf16_t *__restrict__ R, bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP, int npos,
                              const int32_t *__restrict__ cnt)
 {
-    constexpr int CIN = 256, NCC = 8, NSP = 3, SLAB_BYTES = NSP * 128 * 64;
+    constexpr int CIN = 256, NCC = 8, NPIECES = NPW == 6 ? 24 : 27, SLAB_BYTES = NPIECES * 1024;
+    constexpr int V6_TABLES = V6_SLAB0 + 2 * SLAB_BYTES, V6_LDS_BYTES = V6_TABLES + 2048;
+    static_assert(NPW == 6 || NPW == 7, "24 or 27 slab pieces");
+    static_assert(V6_LDS_BYTES <= 81920 && V6_TABLES >= 4 * 18432, "two workgroups per 160 KB; the epilogue's staging fits below the tables");
     int nwg = gridDim.x;
     if (cnt) {
         const int nb = *cnt;
@@ -703,10 +707,11 @@ void k_conv3x3_c256_bf16_duo(const bf16_t *__restrict__ X, const bf16_t *__restr
         const int r = wave * 32 + q * 16 + frow;
         woff[q] = (cout0 + r) * 9 * CIN + ((fslot ^ (((r >> 2) & 1) << 1)) << 3);
     }
-    int soff[6];   // slab: wave w fills the 16-row pieces w + 4*i
+    int soff[NPW];   // slab: wave w fills the 16-row pieces w + 4*i
+    const int last_piece = min(wave + 4 * (NPW - 1), NPIECES - 1);
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const int sr = (wave + 4 * i) * 16 + frow;
+    for (int i = 0; i < NPW; i++) {
+        const int sr = (i == NPW - 1 ? last_piece : wave + 4 * i) * 16 + frow;
         const int pos = min(pbase + sr, npos - 1);
         soff[i] = pos * CIN + ((fslot ^ (((sr >> 2) & 1) << 1)) << 3);
     }
@@ -731,9 +736,9 @@ void k_conv3x3_c256_bf16_duo(const bf16_t *__restrict__ X, const bf16_t *__restr
         for (int q = 0; q < 2; q++) glds16(Wt + woff[q] + wofs, dst + q * 1024);
     };
     auto issue_slab = [&](int cc) {
-        unsigned char *dst = smem + V6_SLAB0 + (cc & 1) * SLAB_BYTES + wave * 1024;
+        unsigned char *dst = smem + V6_SLAB0 + (cc & 1) * SLAB_BYTES;
 #pragma unroll
-        for (int i = 0; i < 6; i++) glds16(X + soff[i] + cc * 32, dst + i * 4096);
+        for (int i = 0; i < NPW; i++) glds16(X + soff[i] + cc * 32, dst + (i == NPW - 1 ? last_piece : wave + 4 * i) * 1024);
     };
 
     issue_slab(0); issue_w(0, 0); issue_w(0, 1);
@@ -743,9 +748,9 @@ void k_conv3x3_c256_bf16_duo(const bf16_t *__restrict__ X, const bf16_t *__restr
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             // this wave's share of W(h), h = 9*cc + tap, (and of the chunk's slab) has landed; younger loads may stay in flight: W(h+1), and
-            // the 6 slab pieces issued one or two half-steps ago
+            // the NPW slab pieces issued one or two half-steps ago
             if (cc == NCC - 1 && tap == 8) wait_vmcnt<0>();
-            else if (cc < NCC - 1 && (tap == 1 || tap == 2)) wait_vmcnt<2 + 6>();
+            else if (cc < NCC - 1 && (tap == 1 || tap == 2)) wait_vmcnt<2 + NPW>();
             else wait_vmcnt<2>();
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");  // everybody's share has landed, and everybody is done reading half-step h-1
@@ -824,15 +829,21 @@ static inline void launch_v5_cw(int cs, dim3 g, dim3 blk, hipStream_t st, const 
     else hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<RESID, NSP, 256, 64>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
 }
 
-// the two-workgroups-per-CU form: boards whose slab fits 3 x 128 positions, batches that fill the chip
+// the two-workgroups-per-CU form: boards whose slab fits 384 or 432 positions, batches that fill the chip
 static inline bool launch_v6(const bf16_t *X, const bf16_t *Wt, const float *bias, const bf16_t *R, bf16_t *Y, int M, int HW, int Wd,
                              int PP, hipStream_t st = 0, const int32_t *cnt = nullptr)
 {
-    if (conv_slab_span(HW, Wd, PP) > 3 * 128) return false;
+    const int span = conv_slab_span(HW, Wd, PP);
+    if (span > 27 * 16) return false;
     const int npos = (M / HW) * PP;
     dim3 g(2 * ((M + 255) / 256)), blk(256);
-    if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16_duo<true>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
-    else hipLaunchKernelGGL((k_conv3x3_c256_bf16_duo<false>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+    if (span <= 24 * 16) {
+        if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16_duo<true, 6>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+        else hipLaunchKernelGGL((k_conv3x3_c256_bf16_duo<false, 6>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+    } else {
+        if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16_duo<true, 7>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+        else hipLaunchKernelGGL((k_conv3x3_c256_bf16_duo<false, 7>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+    }
     return true;
 }
 

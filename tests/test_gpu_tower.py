@@ -59,15 +59,16 @@ def _assert_close(p, v, net, NB, x, tol):
     assert np.abs(v - rv.numpy()).max() <= tol, np.abs(v - rv.numpy()).max()
 
 
-# Batches of more than 128 conv tiles (32768 board points) run every tile as one workgroup over all 256 output
-# channels - the instantiation self-play and the benchmark use - together with the one-chunk stem form of the same
-# kernel; 64 boards of 19x19 run the two-way channel split.  The network is evaluated on the whole batch, the fp32
+# Batches of more than 128 conv tiles (32768 board points) run the instantiations self-play and the benchmark use: two
+# workgroups per tile (128 output channels each) with a slab of 24 pieces of 16 positions (19x19) or 27 pieces (the other
+# boards), together with the one-chunk stem form of the one-workgroup kernel; 64 boards of 19x19 run that kernel's
+# two-way channel split.  The network is evaluated on the whole batch, the fp32
 # restatement on boards from its start, middle and (partly filled) last tile.
 @pytest.mark.parametrize("game,H,B", [
-    ("go", 19, 96),        # 136 tiles, slab of 3 x 128 positions
-    ("go", 9, 410),        # 130 tiles, slab of 4 x 128 positions
-    ("reversi", 8, 520),   # 130 tiles, 4 x 128
-    ("mnk", 15, 150),      # 132 tiles
+    ("go", 19, 96),        # 136 tiles, slab of 24 pieces
+    ("go", 9, 410),        # 130 tiles, slab of 27 pieces (a tile spans up to 426 positions)
+    ("reversi", 8, 520),   # 130 tiles, 27 pieces (422 positions)
+    ("mnk", 15, 150),      # 132 tiles, 27 pieces (394 positions)
     ("go", 19, 64),        # 91 tiles: two workgroups per tile (32 channels per wave)
 ])
 def test_full_tile_conv_kernels_match_fp32_reference(game, H, B):
