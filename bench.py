@@ -44,6 +44,69 @@ def measured_traffic(games, board, channels):
             d["source"] + "; measured at %.0f boards per launch, scaled to %.0f" % (d["boards"], games))
 
 
+class PowerSampler:
+    """Reads the GPU's own telemetry (rocm-smi --showmetrics, read-only) a few times while the timed region runs, from a
+    thread of its own: the timed call blocks in the engine with the GIL released.  What limits the conv kernels is the
+    package power limit, so the line carries socket power, the XCDs' shader clocks and the power-limit residency counter
+    beside the roofline figure.  Never fails the bench: no tool / no permission / odd output -> None."""
+
+    KEYS = {"current_socket_power": "socket_power_w", "current_gfxclks": "gfxclk_mhz", "ppt_residency_acc": "power_limit_residency",
+            "socket_thm_residency_acc": "thermal_residency", "average_umc_activity": "memory_controller_activity_pct",
+            "temperature_hotspot": "hotspot_c"}
+
+    def __init__(self, device, delays=(6.0, 14.0, 22.0)):
+        import threading
+        self.device, self.delays, self.samples, self.stop = device, delays, [], threading.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        import subprocess
+        out = subprocess.run(["rocm-smi", "-d", str(self.device), "--showmetrics", "--json"], capture_output=True, text=True, timeout=20)
+        doc = json.loads(out.stdout[out.stdout.index("{"):])
+        card = next(iter(doc.values()))
+        rec = {}
+        for k, v in card.items():
+            for pre, name in self.KEYS.items():
+                if k.startswith(pre):
+                    try:
+                        if isinstance(v, str) and v.strip().startswith("["):
+                            v = json.loads(v.replace("'", '"'))
+                        rec[name] = [float(x) for x in v] if isinstance(v, (list, tuple)) else float(v)
+                    except (TypeError, ValueError):
+                        pass
+        return rec
+
+    def _run(self):
+        t0 = time.perf_counter()
+        for d in self.delays:
+            if self.stop.wait(max(0.0, d - (time.perf_counter() - t0))):
+                return
+            try:
+                rec = self._read()
+                rec["t_s"] = round(time.perf_counter() - t0, 1)
+                self.samples.append(rec)
+            except Exception:  # noqa: BLE001 - telemetry is optional
+                return
+
+    def start(self):
+        self.thread.start()
+
+    def finish(self):
+        self.stop.set()
+        self.thread.join(timeout=25)
+        if not self.samples:
+            return None
+        out = {"source": "rocm-smi --showmetrics sampled during the timed region", "samples": self.samples}
+        try:
+            lim = __import__("subprocess").run(["rocm-smi", "-d", str(self.device), "--showmaxpower", "--json"], capture_output=True,
+                                               text=True, timeout=20).stdout
+            card = next(iter(json.loads(lim[lim.index("{"):]).values()))
+            out["power_limit_w"] = float(next(iter(card.values())))
+        except Exception:  # noqa: BLE001
+            pass
+        return out
+
+
 def cpu_baseline(game, H, k, num_blocks, channels, sims, budget_s=12.0):
     """The CPU oracle (C port of the reference's rules/search) driving an fp32 PyTorch-CPU restatement of the network,
     one leaf per evaluation as the reference's per-game search sees it.  Two shapes, a bounded sample each: P single-thread
@@ -183,10 +246,14 @@ def main():
     eng.selfplay_run(warm_rounds)
     eng.counters_reset()
     barrier()
+    sampler = PowerSampler(local_rank) if rank == 0 else None
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     eng.selfplay_run(rounds)
     barrier()
     dt = time.perf_counter() - t0
+    gpu_telemetry = sampler.finish() if sampler else None
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -251,6 +318,7 @@ def main():
             },
             # HBM-side kernels: algorithmic bytes from the engine's counters / kernel time (HIP events around each phase)
             "hbm_kernels": hbm_kernels(c, H * H, O, rounds),
+            "gpu_telemetry": gpu_telemetry,
             "tower_tflops_end_to_end": (c["tower_evals"] * eng.tower_flops_per_eval()) / (c["tower_ms"] * 1e-3) / 1e12 if c["tower_ms"] > 0 else 0.0,
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only; at N>1 the other ranks would idle behind it
