@@ -432,18 +432,26 @@ void launch_conv<float>(const Tower *t, const float *X, const float *Wt, const f
         hipLaunchKernelGGL((k_conv3x3_f32<false>), grid, block, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C);
 }
 
-// One pass of `B` boards through all layers.  `alias`: the second convolution of a block writes its output over its
-// residual input (each output element depends on the residual at that element only and nobody else reads it), so two
-// activation buffers are live instead of three.
+// The tower in three stages, so that a large batch can take the middle one in groups of boards:
+//   tower_planes  int8 planes of `B` boards -> the 32-channel NHWC input (rows / count as the caller gave them)
+//   tower_layers  stem, residual blocks and the heads' 1x1 convolutions for the `B` boards that start at board `first` of the
+//                 input and head buffers; the 256-channel activations always start at the buffers' beginning.  `alias`: the
+//                 second convolution of a block writes its output over its residual input (each output element depends on the
+//                 residual at that element only and nobody else reads it), so two activation buffers are live, not three.
+//   tower_head_fc policy / value fully connected layers of `B` boards into the caller's rows
 template <typename T>
-static int forward_pass(Tower *t, const int8_t *planes, int B, float *priors, float *values, hipStream_t st, const int32_t *rows,
-                        const int32_t *cnt, bool alias)
+static void tower_planes(Tower *t, const int8_t *planes, int B, hipStream_t st, const int32_t *rows, const int32_t *cnt)
+{
+    const int ysplit = B < 64 ? 8 : 1;  // few boards: several workgroups per board in the memory-bound kernels
+    hipLaunchKernelGGL((k_planes_to_nhwc<T>), dim3(B, ysplit), dim3(256), 0, st, planes, (T *)t->X0, t->H, t->W, rows, cnt);
+}
+
+template <typename T>
+static void tower_layers(Tower *t, int B, size_t first, hipStream_t st, const int32_t *cnt, bool alias)
 {
     const size_t C = t->C;
-    T *X0 = (T *)t->X0, *X = (T *)t->X, *Tm = (T *)t->T, *Y = alias ? X : (T *)t->Y;
-    float *hp = t->hp, *hv = t->hv;
-    const int ysplit = B < 64 ? 8 : 1;  // few boards: several workgroups per board in the memory-bound kernels
-    hipLaunchKernelGGL((k_planes_to_nhwc<T>), dim3(B, ysplit), dim3(256), 0, st, planes, X0, t->H, t->W, rows, cnt);
+    T *X0 = (T *)t->X0 + first * t->PP * CIN0, *X = (T *)t->X, *Tm = (T *)t->T, *Y = alias ? X : (T *)t->Y;
+    float *hp = t->hp + first * 2 * t->HW, *hv = t->hv + first * t->HW;
     launch_conv<T>(t, X0, (const T *)t->w_stem, t->b_stem, (const T *)nullptr, X, B, CIN0, st, cnt);
     for (int l = 0; l < t->NB; l++) {
         const T *w1 = (const T *)t->w_conv + (size_t)(2 * l) * C * 9 * C;
@@ -456,20 +464,23 @@ static int forward_pass(Tower *t, const int8_t *planes, int B, float *priors, fl
         if (prof) hipEventRecord(t->evs[t->evs_used++], st);
         T *tmp = X; X = Y; Y = tmp;
     }
-    {
-        const int chunks = (int)C / (16 / (int)sizeof(T));  // 16-byte pieces per board point
-        int lpp = 64;
-        while (chunks % lpp) lpp >>= 1;                     // largest power of two <= 64 dividing it
-        if (chunks == lpp)
-            hipLaunchKernelGGL((k_head_conv<T, true>), dim3(B, ysplit), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, hp, hv, t->HW,
-                               t->W, t->PP, (int)C, lpp, cnt);
-        else
-            hipLaunchKernelGGL((k_head_conv<T, false>), dim3(B, ysplit), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, hp, hv, t->HW,
-                               t->W, t->PP, (int)C, lpp, cnt);
-    }
-    hipLaunchKernelGGL(k_head_fc, dim3((B + FCB - 1) / FCB), dim3(384), 0, st, hp, hv, t->w_pfc, t->b_pfc, t->w_v1, t->b_v1, t->w_v2,
+    const int chunks = (int)C / (16 / (int)sizeof(T));  // 16-byte pieces per board point
+    int lpp = 64;
+    while (chunks % lpp) lpp >>= 1;                     // largest power of two <= 64 dividing it
+    // one workgroup per board reads 185 KB (19x19) at a time; below about 4 workgroups per compute unit the boards are cut
+    const int ysplit = B < 64 ? 8 : (B < 4 * t->cus ? 4 : 1);
+    if (chunks == lpp)
+        hipLaunchKernelGGL((k_head_conv<T, true>), dim3(B, ysplit), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, hp, hv, t->HW,
+                           t->W, t->PP, (int)C, lpp, cnt);
+    else
+        hipLaunchKernelGGL((k_head_conv<T, false>), dim3(B, ysplit), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, hp, hv, t->HW,
+                           t->W, t->PP, (int)C, lpp, cnt);
+}
+
+static void tower_head_fc(Tower *t, int B, float *priors, float *values, hipStream_t st, const int32_t *rows, const int32_t *cnt)
+{
+    hipLaunchKernelGGL(k_head_fc, dim3((B + FCB - 1) / FCB), dim3(384), 0, st, t->hp, t->hv, t->w_pfc, t->b_pfc, t->w_v1, t->b_v1, t->w_v2,
                        t->b_v2, priors, values, t->HW, t->O, B, rows, cnt);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // Boards per group for a batch of B boards (0: the whole batch in one pass).  The 256-channel bf16 tower moves three
@@ -503,16 +514,19 @@ static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float
                      const int32_t *cnt)
 {
     const int g = tower_group_boards(t, B);
-    if (g == 0) return forward_pass<T>(t, planes, B, priors, values, st, rows, cnt, false);
-    const int n = (B + g - 1) / g;
-    if (cnt) hipLaunchKernelGGL(k_group_counts, dim3(1), dim3(MAX_GROUPS), 0, st, cnt, t->gcnt, g, n);
-    for (int i = 0; i < n; i++) {
-        const int b0 = i * g, nb = B - b0 < g ? B - b0 : g;
-        // with a row map the i-th group's boards are rows[b0 ...] of the caller's arrays, otherwise rows b0 ...
-        const int rc = forward_pass<T>(t, rows ? planes : planes + (size_t)b0 * 17 * t->HW, nb, rows ? priors : priors + (size_t)b0 * t->O,
-                                       rows ? values : values + b0, st, rows ? rows + b0 : nullptr, cnt ? t->gcnt + i : nullptr, true);
-        if (rc) return rc;
+    tower_planes<T>(t, planes, B, st, rows, cnt);
+    if (g == 0) {
+        tower_layers<T>(t, B, 0, st, cnt, false);
+    } else {
+        // the i-th group holds boards i*g ... of the batch (of the compacted batch when the caller lists rows)
+        const int n = (B + g - 1) / g;
+        if (cnt) hipLaunchKernelGGL(k_group_counts, dim3(1), dim3(MAX_GROUPS), 0, st, cnt, t->gcnt, g, n);
+        for (int i = 0; i < n; i++) {
+            const int b0 = i * g;
+            tower_layers<T>(t, B - b0 < g ? B - b0 : g, (size_t)b0, st, cnt ? t->gcnt + i : nullptr, true);
+        }
     }
+    tower_head_fc(t, B, priors, values, st, rows, cnt);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
