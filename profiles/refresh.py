@@ -46,7 +46,7 @@ bl = json.loads(bench)
 boards = bl["roofline"]["boards_per_launch"]
 f = run(os.path.join(HERE, "pmc_summary.py"), os.path.join(PC, "pmc_fetch", "fetch_counter_collection.csv"))
 w = run(os.path.join(HERE, "pmc_summary.py"), os.path.join(PC, "pmc_write", "write_counter_collection.csv"))
-fp, fr, ws = val(f, "duo<false>"), val(f, "duo<true>"), val(w, "duo<true>")
+fp, fr, ws = val(f, "duo<false"), val(f, "duo<true"), val(w, "duo<true")
 rd, wr = 2 * (fp + fr) / 2 * 1024 / 1e6, ws * 1024 / 1e6
 a_in, a_out = boards * 441 * 512 / 1e6, boards * 361 * 512 / 1e6
 hdr2 = ("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 0 --rounds-per-step 2 --no-cpu-baseline   "
