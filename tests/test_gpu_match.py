@@ -66,6 +66,33 @@ def test_two_network_routing_is_exact(H, C, dtype, G, P, max_turn):
         e.close()
 
 
+def test_match_with_towers_in_board_groups_is_bit_identical(monkeypatch):
+    """Two networks, queued rounds (batch sizes in device memory), each tower taking its share through the layers in groups
+    of 420 boards - the same convolution kernel as the whole batch gets, so whole games must come out bit for bit the same
+    as with whole-batch launches.  The second tower runs beside the first on its own stream in both."""
+    from alphazero_amd.engine import Engine
+    H, G, P, max_turn, NB = 9, 1680, 3, 5, 1
+    O = H * H + 1
+    blob_a, blob_b = _blobs(H, H, O, NB, 256)
+    first = np.resize(np.array([0, 1, 1, 0, 1], np.int32), G)
+    out = []
+    for group in ("420", "-1"):
+        monkeypatch.setenv("AZ_TOWER_GROUP_BOARDS", group)
+        eng = Engine("go", H, H, n_slots=G, max_playout=P, transform_types=8, dirichlet_before=4, max_turn=max_turn,
+                     record_trajectories=True, seed=21, num_blocks=NB, channels=256, tower_dtype="bf16")
+        eng.tower_load(blob_a, net=0)
+        eng.tower_load(blob_b, net=1)
+        eng.selfplay_start()
+        eng.match_assign(np.arange(G), first)
+        eng.selfplay_run((max_turn + 3) * (P + 1))
+        plies, done = eng.selfplay_status()
+        assert np.all(done == 1)
+        out.append([eng.trajectory_pop(s) for s in range(G)])
+        eng.close()
+    for a, b in zip(*out):
+        assert np.array_equal(a["moves"], b["moves"]) and np.array_equal(a["visits"], b["visits"]) and a["winner"] == b["winner"]
+
+
 def test_batched_match_counts_like_the_reference():
     import yaml
     import os
