@@ -62,11 +62,16 @@ class PowerSampler:
     def _read(self):
         import subprocess
         out = subprocess.run(["rocm-smi", "-d", str(self.device), "--showmetrics", "--json"], capture_output=True, text=True, timeout=20)
-        doc = json.loads(out.stdout[out.stdout.index("{"):])
+        return self.parse(out.stdout)
+
+    @classmethod
+    def parse(cls, text):
+        """The fields of KEYS out of `rocm-smi --showmetrics --json` output (one card; warnings may precede the JSON)."""
+        doc = json.loads(text[text.index("{"):])
         card = next(iter(doc.values()))
         rec = {}
         for k, v in card.items():
-            for pre, name in self.KEYS.items():
+            for pre, name in cls.KEYS.items():
                 if k.startswith(pre):
                     try:
                         if isinstance(v, str) and v.strip().startswith("["):

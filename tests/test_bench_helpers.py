@@ -37,3 +37,13 @@ def test_slot_count_for_whole_rounds_of_conv_tiles():
         m = slots_for_whole_tile_rounds(n, 9, 9)
         rounds = (n * 81) // 65536
         assert m <= n and (m == n if rounds == 0 else m * 81 <= rounds * 65536 < (m + 3) * 81)   # (whole boards per group)
+
+
+def test_gpu_telemetry_parser_reads_rocm_smi_json():
+    text = ('WARNING: AMD GPU device(s) is/are in a low-power state.\n{"card0": {"temperature_hotspot (C)": "58", "average_umc_activity (%)": "7", '
+            '"current_socket_power (W)": "1355", "current_gfxclks (MHz)": "[\'2103\', \'2051\', \'N/A\']", "ppt_residency_acc (Count)": "644259", '
+            '"socket_thm_residency_acc (Count)": "0", "average_socket_power (W)": "N/A", "jpeg_activity (%)": "[\'N/A\']"}}')
+    rec = bench.PowerSampler.parse(text)
+    assert rec["socket_power_w"] == 1355.0 and rec["hotspot_c"] == 58.0 and rec["memory_controller_activity_pct"] == 7.0
+    assert rec["power_limit_residency"] == 644259.0 and rec["thermal_residency"] == 0.0
+    assert "gfxclk_mhz" not in rec                    # a list with an unreadable entry is dropped, not half-read
