@@ -14,6 +14,9 @@ for it in range(40):
     e.tower_load(blob); e.tower_load(blob, net=1)
     e.tower_forward(x[:3]); e.tower_forward(x)
     e.selfplay_start(); e.selfplay_run(30)
+    e.match_assign(np.arange(300), np.arange(300) % 2)   # two towers side by side: the second stream and its events
+    e.tower_profile(8)                                   # sampled per-launch timing: the tower's event pool
+    e.selfplay_run(20)
     pl, dn = e.selfplay_status()
     e.rng_inject(0, [1, 2, 3], [0.5], [0.1])
     e.close()
