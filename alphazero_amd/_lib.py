@@ -17,6 +17,7 @@ GAME_IDS = {"go": 0, "reversi": 1, "mnk": 2}
 
 class AzConfig(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("game", C.c_int32), ("board_height", C.c_int32), ("board_width", C.c_int32), ("k", C.c_int32),
         ("n_slots", C.c_int32), ("max_playout", C.c_int32), ("transform_types", C.c_int32),
         ("dirichlet_before", C.c_int32), ("max_turn", C.c_int32),
@@ -26,6 +27,9 @@ class AzConfig(C.Structure):
         ("num_blocks", C.c_int32), ("channels", C.c_int32), ("tower_dtype", C.c_int32), ("device", C.c_int32),
         ("leaves_per_round", C.c_int32), ("virtual_loss", C.c_double),
         ("tree_full_policy", C.c_int32), ("search_f64", C.c_int32), ("enforce_superko", C.c_int32),
+        ("c_punt", C.c_double),
+        ("tower_no_graphs", C.c_int32), ("tower_no_duo", C.c_int32), ("tower_group_boards", C.c_int32),
+        ("match_serial_towers", C.c_int32),
     ]
 
 
@@ -60,6 +64,7 @@ _I = C.c_int32
 # name -> (restype, argtypes); every symbol include/az_engine.h declares
 SIGNATURES = {
     "az_engine_create": (_P, [C.POINTER(AzConfig)]),
+    "az_abi_sizes": (None, [_P]),
     "az_engine_destroy": (None, [_P]),
     "az_last_error": (C.c_char_p, [_P]),
     "az_engine_dims": (_I, [_P, _P, _P, _P]),
@@ -83,6 +88,7 @@ SIGNATURES = {
     "az_search_advance": (_I, [_P, _P, _I, _P]),
     "az_search_tree_size": (_I, [_P, _I, _I, _P, _P]),
     "az_search_grow_trees": (_I, [_P, _I, _I]),
+    "az_search_set_c_punt": (_I, [_P, C.c_double]),
     "az_selfplay_start": (_I, [_P]),
     "az_selfplay_run": (_I, [_P, _I]),
     "az_selfplay_select": (_I, [_P, _P]),
@@ -97,6 +103,7 @@ SIGNATURES = {
     "az_rng_cursor": (_I, [_P, _I, _P, _P, _P]),
     "az_tower_blob_floats": (C.c_size_t, [_P]),
     "az_tower_load_weights": (_I, [_P, _P, C.c_size_t]),
+    "az_tower_load_weights_dev": (_I, [_P, _I, _P, C.c_size_t]),
     "az_search_step_finish_f64": (_I, [_P, _P, _P]),
     "az_selfplay_finish_f64": (_I, [_P, _P, _P]),
     "az_search_root_stats_f64": (_I, [_P, _I, _I, _P, _P, _P, _P, _P]),
@@ -106,6 +113,7 @@ SIGNATURES = {
     "az_tower_forward": (_I, [_P, _P, _I, _P, _P]),
     "az_tower_forward_dev": (_I, [_P, _P, _I, _P, _P]),
     "az_tower_flops_per_eval": (C.c_double, [_P]),
+    "az_tower_conv_kernel": (C.c_char_p, [_P]),
     "az_search_run": (_I, [_P, _I]),
     "az_tower_profile": (_I, [_P, _I]),
     "az_tower_leaf_compaction": (_I, [_P, _I]),
@@ -130,5 +138,11 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        sizes = (C.c_int32 * 3)()
+        L.az_abi_sizes(sizes)
+        mine = (C.sizeof(AzConfig), C.sizeof(AzStateBlob), C.sizeof(AzCounters))
+        if tuple(sizes) != mine:
+            raise ImportError("alphazero_amd: %s was built from another include/az_engine.h (struct sizes %s, binding %s): rebuild it"
+                              % (LIB_PATH, tuple(sizes), mine))
         _lib = L
     return _lib

@@ -70,6 +70,7 @@ struct Dev {
     int G;
     int max_playout, transform_on, transform_types, dirichlet_before, max_turn;
     double d_alpha, d_epsilon;
+    double c_punt;       // exploration constant of the selection score (search/mcts.py:9)
     int EC, BC, MAXD;
     int rng_replay, record, traj_plies;
     // Several leaves of one tree per round (not in the reference, which has one playout in flight; changes visit

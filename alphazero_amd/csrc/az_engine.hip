@@ -69,7 +69,7 @@ struct az_engine {
     hipEvent_t ev[AZ_EVQ][4];
     int ev_head = 0, ev_pending = 0;
     bool conv_profile = false;      // per-launch conv timing on every round (host waits for each round)
-    bool serial_towers = getenv("AZ_MATCH_SERIAL_TOWERS") != nullptr;  // A/B timing: both towers of a match on one stream
+    bool serial_towers = false;     // az_config.match_serial_towers (A/B timing: both towers of a match on one stream)
     int prof_every = 0;             // > 0: per-launch conv timing on every prof_every-th round only, rounds stay queued
     bool ev_prof[AZ_EVQ] = {};      // the queued round of this event quad carries the tower's per-launch events
     uint64_t round_index = 0;
@@ -139,17 +139,33 @@ static int grow_trees(az_engine *h, long long new_ec, long long new_bc)
         {(void **)&D.bStart, 4, false}, {(void **)&D.bCount, 4, false}, {(void **)&D.bOwner, 4, false},
         {(void **)&D.bParent, 4, false}, {(void **)&D.bMap, 4, false}, {(void **)&D.bShift, 4, false},
     };
-    for (Arr &a : arrs) {
+    // all new arrays are allocated and filled before anything of the engine changes: a failed allocation or copy leaves the
+    // old arenas, their strides and the trees in them exactly as they were
+    constexpr int NA = sizeof(arrs) / sizeof(arrs[0]);
+    void *fresh[NA] = {};
+    auto undo = [&]() { for (void *q : fresh) if (q) hipFree(q); };
+    for (int i = 0; i < NA; i++) {
+        const Arr &a = arrs[i];
         const size_t oc = a.edge ? (size_t)D.EC : (size_t)D.BC, nc = a.edge ? (size_t)new_ec : (size_t)new_bc;
         if (oc == nc) continue;
-        void *np_ = nullptr;
-        if (hipMalloc(&np_, T * nc * a.elem) != hipSuccess)
-            return set_err(h, AZ_ERR_HIP, "device allocation failed while enlarging the tree arenas");
-        HIPCHK(hipMemcpy2D(np_, nc * a.elem, *a.p, oc * a.elem, oc * a.elem, T, hipMemcpyDeviceToDevice));
+        if (hipMalloc(&fresh[i], T * nc * a.elem) != hipSuccess) {
+            (void)hipGetLastError();
+            undo();
+            return set_err(h, AZ_ERR_HIP, "device allocation failed while enlarging the tree arenas (the trees are unchanged)");
+        }
+        const hipError_t e = hipMemcpy2D(fresh[i], nc * a.elem, *a.p, oc * a.elem, oc * a.elem, T, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            undo();
+            h->error = std::string("copy into the enlarged tree arenas failed (the trees are unchanged): ") + hipGetErrorString(e);
+            return AZ_ERR_HIP;
+        }
+    }
+    for (int i = 0; i < NA; i++) {
+        if (!fresh[i]) continue;
         for (void *&q : h->allocs)
-            if (q == *a.p) { q = np_; break; }
-        hipFree(*a.p);
-        *a.p = np_;
+            if (q == *arrs[i].p) { q = fresh[i]; break; }
+        hipFree(*arrs[i].p);
+        *arrs[i].p = fresh[i];
     }
     D.EC = (int)new_ec; D.BC = (int)new_bc;
     return AZ_OK;
@@ -204,9 +220,30 @@ extern "C" void az_engine_destroy(az_engine *h)
     delete h;
 }
 
+extern "C" void az_abi_sizes(int32_t out[3])
+{
+    if (!out) return;
+    out[0] = (int32_t)sizeof(az_config); out[1] = (int32_t)sizeof(az_state_blob); out[2] = (int32_t)sizeof(az_counters);
+}
+
+static TowerOptions tower_options(const az_config &c)
+{
+    TowerOptions o;
+    o.graphs = !c.tower_no_graphs; o.duo = !c.tower_no_duo; o.group_boards = c.tower_group_boards;
+    return o;
+}
+
 extern "C" az_engine *az_engine_create(const az_config *cfg)
 {
     if (!cfg) { g_create_error = "null config"; return nullptr; }
+    if (cfg->struct_size != sizeof(az_config)) {   // (the first member: safe to read whatever the caller's struct is)
+        char buf[160];
+        snprintf(buf, sizeof buf, "az_config.struct_size is %u, this library's az_config has %zu bytes: the binding does not match include/az_engine.h",
+                 cfg->struct_size, sizeof(az_config));
+        g_create_error = buf;
+        return nullptr;
+    }
+    if (!(cfg->c_punt >= 0.0)) { g_create_error = "c_punt must be positive (0 = 5.0)"; return nullptr; }
     const int H = cfg->board_height, W = cfg->board_width, NC = H * W;
     if (cfg->game < 0 || cfg->game > 2 || H < 1 || W < 1 || NC > AZ_MAX_CELLS || cfg->n_slots < 1) {
         g_create_error = "bad game / board size / n_slots";
@@ -253,6 +290,8 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     D.dirichlet_before = cfg->dirichlet_before;
     D.max_turn = cfg->max_turn;
     D.d_alpha = cfg->d_alpha; D.d_epsilon = cfg->d_epsilon;
+    D.c_punt = cfg->c_punt > 0.0 ? cfg->c_punt : 5.0;
+    h->serial_towers = cfg->match_serial_towers != 0;
     long long ec = cfg->tree_edge_cap > 0 ? cfg->tree_edge_cap : 3LL * (cfg->max_playout + 1) * O;
     long long bc = cfg->tree_block_cap > 0 ? cfg->tree_block_cap : 8LL * (cfg->max_playout + 1);
     if (ec < O) ec = O;
@@ -328,7 +367,8 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     h->rng_bufs.assign((size_t)3 * G, nullptr);
     if (cfg->num_blocks > 0) {
         std::string terr;
-        h->tower = tower_create(H, W, O, cfg->num_blocks, cfg->channels > 0 ? cfg->channels : 256, cfg->tower_dtype, D.K * G, terr);
+        h->tower = tower_create(H, W, O, cfg->num_blocks, cfg->channels > 0 ? cfg->channels : 256, cfg->tower_dtype, D.K * G,
+                                tower_options(*cfg), terr);
         if (!h->tower) { g_create_error = "tower: " + terr; az_engine_destroy(h); return nullptr; }
     }
     hipLaunchKernelGGL(k_reset, dim3(G), dim3(64), 0, h->stream, D, (const int32_t *)nullptr, G, 0);
@@ -806,6 +846,14 @@ extern "C" int az_search_advance(az_engine *h, const int32_t *slots, int32_t n, 
     return advance(h, slots, n, moves, -1);
 }
 
+extern "C" int az_search_set_c_punt(az_engine *h, double c_punt)
+{
+    if (!h) return AZ_ERR_ARG;
+    if (!(c_punt > 0.0)) return set_err(h, AZ_ERR_ARG, "c_punt must be positive");
+    h->D.c_punt = c_punt;   // the kernels take the engine's parameters by value with every launch
+    return AZ_OK;
+}
+
 extern "C" int az_search_tree_size(az_engine *h, int32_t slot, int32_t side, int32_t *edges, int32_t *blocks)
 {
     if (!h || slot < 0 || slot >= h->D.G || side < 0 || side > 1) return AZ_ERR_ARG;
@@ -1205,10 +1253,26 @@ extern "C" int az_tower_load_weights_net(az_engine *h, int32_t net, const float 
     if (!h->tower2) {
         const az_config &c = h->cfg;
         h->tower2 = tower_create(c.board_height, c.board_width, h->D.geo.O, c.num_blocks, c.channels > 0 ? c.channels : 256, c.tower_dtype,
-                                 h->D.G, terr);
+                                 h->D.G, tower_options(c), terr);
         if (!h->tower2) { h->error = "tower: " + terr; return AZ_ERR_HIP; }
     }
     if (tower_load(h->tower2, blob, n, h->stream, terr) != 0) { h->error = "tower: " + terr; return AZ_ERR_ARG; }
+    return AZ_OK;
+}
+
+extern "C" int az_tower_load_weights_dev(az_engine *h, int32_t net, const float *blob_dev, size_t n)
+{
+    if (!h || !blob_dev || net < 0 || net > 1) return AZ_ERR_ARG;
+    if (!h->tower) return set_err(h, AZ_ERR_ARG, "engine was created with num_blocks = 0 (no tower)");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    std::string terr;
+    if (net == 1 && !h->tower2) {
+        const az_config &c = h->cfg;
+        h->tower2 = tower_create(c.board_height, c.board_width, h->D.geo.O, c.num_blocks, c.channels > 0 ? c.channels : 256, c.tower_dtype,
+                                 h->D.G, tower_options(c), terr);
+        if (!h->tower2) { h->error = "tower: " + terr; return AZ_ERR_HIP; }
+    }
+    if (tower_load_dev(net ? h->tower2 : h->tower, blob_dev, n, h->stream, terr) != 0) { h->error = "tower: " + terr; return AZ_ERR_ARG; }
     return AZ_OK;
 }
 
@@ -1314,6 +1378,13 @@ extern "C" int az_tower_leaf_compaction(az_engine *h, int32_t on)
     HIPCHK(hipStreamSynchronize(h->stream));
     h->compact = on != 0;
     return AZ_OK;
+}
+
+extern "C" const char *az_tower_conv_kernel(az_engine *h)
+{
+    if (!h || !h->tower) return "";
+    const int LG = h->D.K * h->D.G;
+    return tower_conv_kernel_name(h->tower, LG, tower_takes_device_count(h->tower, LG));
 }
 
 extern "C" double az_tower_flops_per_eval(az_engine *h) { return (h && h->tower) ? tower_flops_per_eval(h->tower) : 0.0; }

@@ -203,6 +203,7 @@ __device__ __forceinline__ void select_one(const Dev &D, const int sub, WLds &L)
             // AZ_NJ * 64 children: all their statistics are requested before any is used (one memory latency per level,
             // not one per 64 children); a slot past the end re-reads the last child and is ignored.
             R sq = (R)sqrt((double)parentN);
+            const R cp = (R)D.c_punt;
             int cN[AZ_NJ];
             R cW[AZ_NJ], cP[AZ_NJ];
 #pragma unroll
@@ -216,7 +217,7 @@ __device__ __forceinline__ void select_one(const Dev &D, const int sub, WLds &L)
             for (int j = 0; j < AZ_NJ; j++) {
                 const int c = lane + j * AZ_WAVE;
                 const int N = cN[j];
-                R u = (R)5.0 * cP[j];
+                R u = cp * cP[j];
                 u = u * sq;
                 u = u / ((R)1.0 + (R)N);
                 R q = N == 0 ? (R)0.0 : cW[j] / (R)N;

@@ -9,6 +9,7 @@
 #include "az_tower.h"
 
 #include <hip/hip_bf16.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -54,7 +55,7 @@ struct Tower {
     struct Graph { const void *planes; const void *priors, *values, *rows; int B; hipStream_t st; hipGraphExec_t exec; };
     std::vector<Graph> graphs;
     bool use_graphs;
-    bool use_duo;   // two-workgroups-per-CU conv kernel where it applies (AZ_CONV_DUO=0 switches it off: A/B timing only)
+    bool use_duo;   // two-workgroups-per-CU conv kernel where it applies (off: A/B timing only)
     // large batches go through the tower in groups of boards (see forward_t): group size in boards (0 = automatic,
     // -1 = never), per-group device-side counts, boards of every profiled launch
     int group_boards, cus;
@@ -278,7 +279,7 @@ double tower_flops_per_eval(const Tower *t)
 
 double tower_conv_flops_per_launch(const Tower *t, int B) { return 2.0 * (double)B * t->HW * 9.0 * t->C * t->C; }
 
-Tower *tower_create(int H, int W, int O, int num_blocks, int channels, int dtype, int max_batch, std::string &err)
+Tower *tower_create(int H, int W, int O, int num_blocks, int channels, int dtype, int max_batch, const TowerOptions &opt, std::string &err)
 {
     if (channels % 128 != 0) { err = "channels must be a multiple of 128"; return nullptr; }
     if (H * W > 361) { err = "board too large"; return nullptr; }
@@ -286,9 +287,7 @@ Tower *tower_create(int H, int W, int O, int num_blocks, int channels, int dtype
     t->H = H; t->W = W; t->HW = H * W; t->PP = (H + 2) * (W + 2); t->O = O; t->NB = num_blocks; t->C = channels;
     t->dtype = dtype; t->maxB = max_batch; t->ready = false;
     t->profile = false; t->evs_used = 0; t->conv_ms = 0; t->conv_launches = 0;
-    t->use_graphs = getenv("AZ_NO_GRAPHS") == nullptr;  // the variable only serves A/B timing
-    { const char *e = getenv("AZ_CONV_DUO"); t->use_duo = !(e && e[0] == '0'); }
-    { const char *e = getenv("AZ_TOWER_GROUP_BOARDS"); t->group_boards = e ? atoi(e) : 0; }  // tests and A/B timing
+    t->use_graphs = opt.graphs; t->use_duo = opt.duo; t->group_boards = opt.group_boards;
     t->conv_flops = 0;
     {
         int dev = 0, cus = 0;
@@ -373,6 +372,85 @@ int tower_load(Tower *t, const float *blob, size_t n, hipStream_t st, std::strin
     rc |= upload_conv(t->w_v2, p, 256, 0, st); p += 256;
     rc |= upload_conv(t->b_v2, p, 1, 0, st); p += 1;
     if (rc) { err = "weight upload failed"; return -1; }
+    t->ready = true;
+    return 0;
+}
+
+// Weights from a blob that already lies in device memory.  k_weights_cvt: n floats -> the compute type (bf16 with the same
+// round-to-nearest-even, NaN kept quiet, as h_f2bf on the host; float32 copied).  k_stem_pad: the stem's [C][9][17] rows
+// padded with zeros to [C][9][CIN0].
+template <typename T>
+__global__ void k_weights_cvt(const float *__restrict__ src, T *__restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if constexpr (sizeof(T) == 2) {
+            unsigned u = __float_as_uint(src[i]);
+            if ((u & 0x7fffffffu) > 0x7f800000u) dst[i] = (T)((u >> 16) | 0x40);
+            else { u += 0x7fffu + ((u >> 16) & 1u); dst[i] = (T)(u >> 16); }
+        } else {
+            dst[i] = src[i];
+        }
+    }
+}
+
+template <typename T>
+__global__ void k_stem_pad(const float *__restrict__ src, T *__restrict__ dst, int rows)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * CIN0) return;
+    const int r = i / CIN0, ci = i - r * CIN0;
+    const float f = ci < 17 ? src[(size_t)r * 17 + ci] : 0.0f;
+    if constexpr (sizeof(T) == 2) {
+        unsigned u = __float_as_uint(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) dst[i] = (T)((u >> 16) | 0x40);
+        else { u += 0x7fffu + ((u >> 16) & 1u); dst[i] = (T)(u >> 16); }
+    } else {
+        dst[i] = f;
+    }
+}
+
+template <typename T>
+static void load_dev_t(Tower *t, const float *p, hipStream_t st)
+{
+    const size_t C = t->C, HW = t->HW, O = t->O;
+    auto cvt = [&](void *dst, const float *src, size_t n) {
+        const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL((k_weights_cvt<T>), dim3(blocks), dim3(256), 0, st, src, (T *)dst, n);
+    };
+    auto cpy = [&](float *dst, const float *src, size_t n) { hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st); };
+    hipLaunchKernelGGL((k_stem_pad<T>), dim3(((unsigned)(C * 9 * CIN0) + 255) / 256), dim3(256), 0, st, p, (T *)t->w_stem, (int)(C * 9));
+    p += C * 9 * 17;
+    cpy(t->b_stem, p, C); p += C;
+    for (int l = 0; l < 2 * t->NB; l++) {
+        cvt((T *)t->w_conv + (size_t)l * C * 9 * C, p, C * 9 * C); p += C * 9 * C;
+        cpy(t->b_conv + (size_t)l * C, p, C); p += C;
+    }
+    cpy(t->w_head, p, 3 * C); p += 3 * C;
+    cpy(t->b_head, p, 3); p += 3;
+    cpy(t->w_pfc, p, 2 * HW * O); p += 2 * HW * O;
+    cpy(t->b_pfc, p, O); p += O;
+    cpy(t->w_v1, p, HW * 256); p += HW * 256;
+    cpy(t->b_v1, p, 256); p += 256;
+    cpy(t->w_v2, p, 256); p += 256;
+    cpy(t->b_v2, p, 1);
+}
+
+int tower_load_dev(Tower *t, const float *dev_blob, size_t n, hipStream_t st, std::string &err)
+{
+    if (n != t->blob_floats) {
+        char buf[128];
+        snprintf(buf, sizeof buf, "weight blob has %zu floats, expected %zu", n, t->blob_floats);
+        err = buf;
+        return -1;
+    }
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, dev_blob) != hipSuccess || at.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        err = "blob_dev is not a device pointer";
+        return -1;
+    }
+    if (t->dtype == 1) load_dev_t<bf16_t>(t, dev_blob, st); else load_dev_t<float>(t, dev_blob, st);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { err = "device-side weight load failed"; return -1; }
     t->ready = true;
     return 0;
 }
@@ -528,6 +606,22 @@ static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float
     }
     tower_head_fc(t, B, priors, values, st, rows, cnt);
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Which convolution kernel launch_conv picks for the residual layers of a batch of B boards (the tower's groups of boards
+// taken into account): the name a profiler shows, for labelling measurements.
+const char *tower_conv_kernel_name(const Tower *t, int B, bool device_count)
+{
+    if (t->dtype != 1) return "k_conv3x3_f32 (vector ALU, float32 operands, float64 accumulation)";
+    const int g = tower_group_boards(t, B);
+    const int M = (g ? g : B) * t->HW;
+    if (!device_count && M <= SMALL_BATCH_POINTS && t->C % 64 == 0) return "k_conv3x3_bf16_small (32 points x 32/64 channels per workgroup, reduction axis split over the waves)";
+    if (t->C != 256) return "k_conv3x3_bf16 (per-tap gather, bf16 MFMA 16x16x32)";
+    const int span = conv_slab_span(t->HW, t->W, t->PP);
+    if (t->use_duo && conv_channel_split(M) == 1 && span <= 27 * 16)
+        return "k_conv3x3_c256_bf16_duo (3x3 256->256 implicit GEMM, bf16 MFMA 16x16x32, two 4-wave workgroups per CU)";
+    if (span <= 4 * 128) return "k_conv3x3_c256_bf16_slab (3x3 256->256 implicit GEMM, bf16 MFMA 16x16x32, one 8-wave workgroup per CU)";
+    return "k_conv3x3_c256_bf16 (per-tap gather of both operands, bf16 MFMA 16x16x32)";
 }
 
 bool tower_takes_device_count(const Tower *t, int B)

@@ -1,5 +1,6 @@
 """Python handle on one GPU's batched self-play engine (thin layer over the C ABI)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -52,14 +53,32 @@ class Engine:
                  dirichlet_before=30, max_turn=400, d_alpha=0.03, d_epsilon=0.25, tree_edge_cap=0, tree_block_cap=0,
                  max_depth=0, rng_replay=False, seed=0, record_trajectories=False, num_blocks=0, channels=256,
                  tower_dtype="bf16", device=0, search_f64=False, tree_full_policy=0, leaves_per_round=1,
-                 virtual_loss=1.0, enforce_superko=False):
+                 virtual_loss=1.0, enforce_superko=False, c_punt=5.0, tower_graphs=None, conv_duo=None,
+                 tower_group_boards=None, match_serial_towers=None):
+        """The last four arguments are measurement switches (A/B timing, tests).  Left at None they follow the
+        environment variables the tools/ scripts set: AZ_NO_GRAPHS, AZ_CONV_DUO=0, AZ_TOWER_GROUP_BOARDS=N,
+        AZ_MATCH_SERIAL_TOWERS; the library itself reads no environment."""
         self._L = _lib.lib()
-        cfg = AzConfig(GAME_IDS[game] if isinstance(game, str) else int(game), board_height, board_width, k, n_slots,
-                       max_playout, transform_types, dirichlet_before, max_turn, d_alpha, d_epsilon, tree_edge_cap,
-                       tree_block_cap, max_depth, int(rng_replay), seed, int(record_trajectories), num_blocks, channels,
-                       {"fp32": 0, "bf16": 1}[tower_dtype] if isinstance(tower_dtype, str) else int(tower_dtype), device,
-                       int(leaves_per_round), float(virtual_loss), int(tree_full_policy), int(bool(search_f64)),
-                       int(bool(enforce_superko)))
+        env = os.environ
+        if tower_graphs is None:
+            tower_graphs = "AZ_NO_GRAPHS" not in env
+        if conv_duo is None:
+            conv_duo = not env.get("AZ_CONV_DUO", "1").startswith("0")
+        if tower_group_boards is None:
+            tower_group_boards = int(env.get("AZ_TOWER_GROUP_BOARDS", "0"))
+        if match_serial_towers is None:
+            match_serial_towers = "AZ_MATCH_SERIAL_TOWERS" in env
+        cfg = AzConfig(
+            struct_size=C.sizeof(AzConfig), game=GAME_IDS[game] if isinstance(game, str) else int(game),
+            board_height=board_height, board_width=board_width, k=k, n_slots=n_slots, max_playout=max_playout,
+            transform_types=transform_types, dirichlet_before=dirichlet_before, max_turn=max_turn, d_alpha=d_alpha,
+            d_epsilon=d_epsilon, tree_edge_cap=tree_edge_cap, tree_block_cap=tree_block_cap, max_depth=max_depth,
+            rng_replay=int(rng_replay), seed=seed, record_trajectories=int(record_trajectories), num_blocks=num_blocks,
+            channels=channels, tower_dtype={"fp32": 0, "bf16": 1}[tower_dtype] if isinstance(tower_dtype, str) else int(tower_dtype),
+            device=device, leaves_per_round=int(leaves_per_round), virtual_loss=float(virtual_loss),
+            tree_full_policy=int(tree_full_policy), search_f64=int(bool(search_f64)), enforce_superko=int(bool(enforce_superko)),
+            c_punt=float(c_punt), tower_no_graphs=int(not tower_graphs), tower_no_duo=int(not conv_duo),
+            tower_group_boards=int(tower_group_boards), match_serial_towers=int(bool(match_serial_towers)))
         self.cfg = cfg
         # dtype of W / P / priors / values: float64 reproduces a search fed by a float64 evaluator (dummy_eval.py:26-28)
         self.real = np.float64 if search_f64 else np.float32
@@ -200,6 +219,12 @@ class Engine:
         """Enlarge every tree's arena (0 = double); contents are kept."""
         self._ck(self._L.az_search_grow_trees(self._h, int(edge_cap), int(block_cap)))
 
+    def set_c_punt(self, c_punt):
+        """Assigning the module global c_punt of the reference's search module (search/mcts.py:9): used from the next
+        selection step on."""
+        self._ck(self._L.az_search_set_c_punt(self._h, float(c_punt)))
+        self.cfg.c_punt = float(c_punt)
+
     def tree_size(self, slot, side):
         e, b = C.c_int32(0), C.c_int32(0)
         self._ck(self._L.az_search_tree_size(self._h, slot, side, C.byref(e), C.byref(b)))
@@ -301,6 +326,14 @@ class Engine:
         else:
             self._ck(self._L.az_tower_load_weights_net(self._h, int(net), b.ctypes.data, b.size))
 
+    def tower_load_torch(self, blob, net=0):
+        """The folded float32 blob as a CUDA tensor on this engine's GPU (what an RCCL broadcast delivers): converted and
+        copied into the tower by kernels, no pass through host memory."""
+        import torch
+        assert blob.is_cuda and blob.dtype == torch.float32 and blob.is_contiguous() and blob.device.index == self.cfg.device
+        torch.cuda.current_stream(blob.device).synchronize()   # the engine reads it on its own stream
+        self._ck(self._L.az_tower_load_weights_dev(self._h, int(net), blob.data_ptr(), blob.numel()))
+
     def match_assign(self, slots, net_of_first):
         """Two-network match: in slots[i] the side moving first is evaluated by network net_of_first[i]
         (evaluator.py:81-84).  Empty `slots` switches back to one network."""
@@ -339,6 +372,10 @@ class Engine:
 
     def tower_leaf_compaction(self, on=True):
         self._ck(self._L.az_tower_leaf_compaction(self._h, int(on)))
+
+    def tower_conv_kernel(self):
+        """Name and description of the conv kernel the residual layers of a self-play round run with."""
+        return self._L.az_tower_conv_kernel(self._h).decode()
 
     def tower_flops_per_eval(self):
         return self._L.az_tower_flops_per_eval(self._h)

@@ -90,7 +90,12 @@ class NNEvaluator:
             self.rwlock.w_release()
 
     def save(self, filename):
-        torch.save(self.net.state_dict(), filename)
+        # a reader of the weights: a load() in another thread (the writer) may not swap them half-way through the file
+        self.rwlock.r_acquire()
+        try:
+            torch.save(self.net.state_dict(), filename)
+        finally:
+            self.rwlock.r_release()
 
     def set_weights(self, state_dict):
         self.rwlock.w_acquire()

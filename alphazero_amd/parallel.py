@@ -2,42 +2,67 @@
 
 Two exchanges exist (they replace the reference's checkpoint-path notification and its
 data_queue / TCP trajectory hand-off, AlphaZero/train/parallel/selfplay.py:82-85,110-122):
-  * broadcast_weights   - rank 0's folded weight blob to every rank (RCCL broadcast on GPU tensors;
-                          gloo on CPU tensors in tests)
+  * broadcast_weights   - rank 0's folded weight blob to every rank (RCCL broadcast on GPU tensors, loaded into the tower
+                          from GPU memory; gloo on CPU tensors in tests)
   * gather_trajectories - finished games of every rank to the rank that owns the replay buffer (rank 0), in a
                           compact form: moves int16, visit counts as sparse (action, count) pairs.  A dense
                           int32 row of a 19x19 game is 1448 bytes per ply and at most max_playout + 1 of its 362
                           entries are non-zero (typically a few dozen); 4000 finished games of 400 plies are
                           2.3 GB dense and 0.1 - 0.4 GB packed.  Everything stays a torch tensor on the caller's
-                          device until rank 0 unpacks it; transfers are point-to-point, chunked.
+                          device until rank 0 unpacks it; transfers are point-to-point, chunked, as bytes.
 """
 import numpy as np
 import torch
 
 
-def broadcast_weights(blob, n_floats, dist=None, device=None):
-    """blob: float32 numpy on rank 0 (ignored elsewhere).  Returns the blob on every rank."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+def _is_gloo(dist):
+    return str(dist.get_backend()).lower() == "gloo"
+
+
+def _wire_device(dist, device):
+    """Where a tensor has to live for this backend to move it: RCCL ("nccl") takes tensors in GPU memory as they are; gloo
+    (CPU tests, and the two-ranks-on-one-card rehearsal, where RCCL refuses a second rank per device) takes host tensors."""
+    if _is_gloo(dist):
+        return torch.device("cpu")
+    if device is None or torch.device(device).type != "cuda":
+        raise ValueError("the nccl backend moves GPU tensors: pass the rank's cuda device")
+    return torch.device(device)
+
+
+def broadcast_weights(blob, n_floats, dist=None, device=None, as_tensor=False):
+    """blob: float32 numpy (or tensor) on rank 0, ignored elsewhere.  Every rank gets the blob: as a float32 numpy array, or,
+    with as_tensor=True, as a tensor on `device` - with RCCL that is the broadcast's own receive buffer, so on a GPU rank the
+    weights never pass through host memory (Engine.tower_load_torch takes it from there)."""
+    single = dist is None or not dist.is_initialized() or dist.get_world_size() == 1
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    if single or dist.get_rank() == 0:
         if blob is None:
             raise ValueError("rank 0 must supply the weight blob")
-        return np.ascontiguousarray(blob, np.float32)
-    dev = device if device is not None else torch.device("cpu")
-    if dist.get_rank() == 0:
-        if blob is None or blob.size != n_floats:
-            raise ValueError("rank 0 blob has the wrong size")
-        t = torch.from_numpy(np.ascontiguousarray(blob, np.float32)).to(dev)
-    else:
-        t = torch.empty(n_floats, dtype=torch.float32, device=dev)
+        src = blob if torch.is_tensor(blob) else torch.from_numpy(np.ascontiguousarray(blob, np.float32))
+        if src.numel() != n_floats or src.dtype != torch.float32:
+            raise ValueError("rank 0 blob has the wrong size or type")
+    if single:
+        t = src.to(dev).contiguous() if as_tensor else src
+        return t if as_tensor else t.cpu().numpy()
+    wire = _wire_device(dist, dev)
+    t = src.to(wire).contiguous() if dist.get_rank() == 0 else torch.empty(n_floats, dtype=torch.float32, device=wire)
     dist.broadcast(t, src=0)
+    if as_tensor:
+        return t.to(dev)
     return t.cpu().numpy()
 
 
 def update_weights(engine, blob, dist=None, device=None, net=0):
-    """The model update of selfplay.py:110-122 for every rank's engine: rank 0 passes the new folded blob (others
-    None), every rank receives it and loads it into its tower; games in flight go on with the new network from the next
-    round.  Returns the blob."""
-    got = broadcast_weights(blob, engine.tower_blob_floats(), dist, device)
-    engine.tower_load(got, net=net)
+    """The model update of selfplay.py:110-122 for every rank's engine: rank 0 passes the new folded blob (others None),
+    every rank receives it and loads it into its tower; games in flight go on with the new network from the next round.
+    With a cuda `device` the blob stays in GPU memory from the broadcast into the tower's weight arrays
+    (az_tower_load_weights_dev).  Returns the blob as this rank holds it (tensor on `device`, or numpy without one)."""
+    on_gpu = device is not None and torch.device(device).type == "cuda" and hasattr(engine, "tower_load_torch")
+    got = broadcast_weights(blob, engine.tower_blob_floats(), dist, device, as_tensor=on_gpu)
+    if on_gpu:
+        engine.tower_load_torch(got, net=net)
+    else:
+        engine.tower_load(got, net=net)
     return got
 
 
@@ -124,30 +149,42 @@ def unpack_trajectories(blob, O=None):
     return out
 
 
-def gather_packed(blob, dist=None, dst=0, chunk_elems=1 << 25):
-    """Every rank's packed tensor to rank `dst`: a tiny all_gather of the lengths, then point-to-point transfers in chunks
-    of chunk_elems int16 (64 MiB).  Returns the list of tensors in rank order on dst, [] elsewhere."""
+def gather_packed(blob, dist=None, dst=0, chunk_bytes=64 << 20):
+    """Every rank's packed tensor to rank `dst`: a tiny all_gather of the lengths, then point-to-point transfers in chunks of
+    chunk_bytes (64 MiB).  Returns the list of int16 tensors in rank order on dst, [] elsewhere.
+    On the wire the blob is plain bytes (a uint8 view): RCCL has no 16-bit integer type.  With RCCL the tensors stay in GPU
+    memory end to end; with gloo a GPU tensor is staged through host memory."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return [blob]
+    if blob.dtype != torch.int16:
+        raise ValueError("a packed trajectory blob is an int16 tensor")
     world, rank, dev = dist.get_world_size(), dist.get_rank(), blob.device
-    n = torch.tensor([blob.numel()], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    wire = _wire_device(dist, dev)
+    chunk = max(2, int(chunk_bytes) & ~1)                       # whole int16 elements per chunk
+    n = torch.tensor([blob.numel() * 2], dtype=torch.int64, device=wire)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=wire) for _ in range(world)]
     dist.all_gather(sizes, n)
     sizes = [int(s.item()) for s in sizes]
     if rank != dst:
-        for a in range(0, blob.numel(), chunk_elems):
-            dist.send(blob[a:a + chunk_elems].contiguous(), dst=dst)
+        raw = wire_bytes(blob).to(wire)
+        for a in range(0, raw.numel(), chunk):
+            dist.send(raw[a:a + chunk], dst=dst)
         return []
     out = []
     for r in range(world):
         if r == dst:
             out.append(blob)
             continue
-        buf = torch.empty(sizes[r], dtype=torch.int16, device=dev)
-        for a in range(0, sizes[r], chunk_elems):
-            dist.recv(buf[a:a + chunk_elems], src=r)
-        out.append(buf)
+        buf = torch.empty(sizes[r], dtype=torch.uint8, device=wire)
+        for a in range(0, sizes[r], chunk):
+            dist.recv(buf[a:a + chunk], src=r)
+        out.append(buf.view(torch.int16).to(dev))
     return out
+
+
+def wire_bytes(blob):
+    """The uint8 view of a packed blob that goes over the wire (same memory, no copy)."""
+    return blob.contiguous().view(torch.uint8)
 
 
 def gather_trajectories(trajs, O, dist=None, device=None, dst=0):

@@ -13,7 +13,9 @@ from numpy.random import randint
 from ..engine import Engine, game_config_to_engine_kwargs
 from .math_helper import random_variate_dirichlet, weighted_random_choice
 
-c_punt = 5.0  # fixed inside the select kernel
+# Exploration constant of the selection score.  As in the reference (search/mcts.py:9, read at :88 on every call), assigning
+# this module global changes the searches that follow: MCTSearch hands the current value to the engine before each search.
+c_punt = 5.0
 
 
 class _LeafView(object):
@@ -122,6 +124,8 @@ class MCTSearch(object):
             self._loaded_version = None
         self._searched = True
         eng = self._eng
+        if eng.cfg.c_punt != float(c_punt):
+            eng.set_c_punt(c_punt)
         eng.state_copy(0, state._eng, state._slot, ref_semantics=False)
         _, n_children, _, _, _ = eng.root_stats(0, 0)
         root_is_leaf = len(n_children) == 0
@@ -155,7 +159,7 @@ class MCTSearch(object):
                 self._f64 = f64
                 if f64:  # nothing is in the trees yet: restart this search on a float64 engine with the same draws
                     eng.close()
-                    eng = self._eng = Engine(**self._eng_kw, search_f64=True)
+                    eng = self._eng = Engine(**self._eng_kw, search_f64=True, c_punt=c_punt)
                     eng.state_copy(0, state._eng, state._slot, ref_semantics=False)
                     eng.rng_inject(0, tids, etas, [])
                     eng.search_begin([0], [0], [int(bool(dirichlet))])

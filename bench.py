@@ -14,6 +14,13 @@ game through the end of a search, the move and the re-root of both trees: `value
 moves completed inside the timed region per second.  Inputs are synthetic: seeded glorot-uniform
 weights, games start from the empty board, device RNG seed 0; everything is resident in HBM before
 the timed region.  Rank 0 prints one JSON line.
+
+`--gpus N` with N > 1 and no RANK in the environment (the plain `python bench.py --gpus N` form) makes this process a
+launcher: before anything touches the GPU it starts N ranks of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one
+GPU each, RCCL between them), lets rank 0 print the line and returns non-zero if any rank fails.  Under torchrun the
+ranks exist already and run directly.  After the timed region (outside it) every run also exercises the two exchanges of
+a multi-GPU self-play job - the weight update and the gather of packed trajectories to rank 0 - and reports their bytes
+and times in `exchange`.
 """
 import argparse
 import json
@@ -25,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS_BF16 = 2500.0  # dense bf16 MFMA peak of one MI355X, TFLOP/s
+VALU_PEAK_TFLOPS_FP32 = 157.3   # float32 vector peak (the fp32 parity tower runs on the vector ALU)
 
 
 def measured_traffic(games, board, channels):
@@ -59,10 +67,26 @@ class PowerSampler:
         self.device, self.delays, self.samples, self.stop = device, delays, [], threading.Event()
         self.thread = threading.Thread(target=self._run, daemon=True)
 
-    def _read(self):
+    SMI = "/opt/rocm/libexec/rocm_smi/rocm_smi.py"
+
+    @classmethod
+    def _smi(cls, *args):
+        """rocm-smi started as `python3 rocm_smi.py` (its own first line goes through `env`, one more exec), with a
+        profiler's preload and tool variables removed from the child's environment."""
         import subprocess
-        out = subprocess.run(["rocm-smi", "-d", str(self.device), "--showmetrics", "--json"], capture_output=True, text=True, timeout=20)
-        return self.parse(out.stdout)
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS"))}
+        if "rocprof" in env.get("LD_PRELOAD", ""):   # only the profiler's own entries go; anything else preloaded stays
+            env["LD_PRELOAD"] = " ".join(x for x in env["LD_PRELOAD"].replace(":", " ").split() if "rocprof" not in x)
+        cmd = [sys.executable, cls.SMI] if os.path.exists(cls.SMI) else ["rocm-smi"]
+        return subprocess.run(cmd + list(args), capture_output=True, text=True, timeout=20, env=env).stdout
+
+    @staticmethod
+    def under_profiler():
+        e = os.environ
+        return any(k.startswith(("ROCP_", "ROCPROF")) for k in e) or "rocprof" in e.get("LD_PRELOAD", "") or "HSA_TOOLS_LIB" in e
+
+    def _read(self):
+        return self.parse(self._smi("-d", str(self.device), "--showmetrics", "--json"))
 
     @classmethod
     def parse(cls, text):
@@ -103,8 +127,7 @@ class PowerSampler:
             return None
         out = {"source": "rocm-smi --showmetrics sampled during the timed region", "samples": self.samples}
         try:
-            lim = __import__("subprocess").run(["rocm-smi", "-d", str(self.device), "--showmaxpower", "--json"], capture_output=True,
-                                               text=True, timeout=20).stdout
+            lim = self._smi("-d", str(self.device), "--showmaxpower", "--json")
             card = next(iter(json.loads(lim[lim.index("{"):]).values()))
             out["power_limit_w"] = float(next(iter(card.values())))
         except Exception:  # noqa: BLE001
@@ -164,7 +187,7 @@ def hbm_kernels(c, cells, O, steps, peak_gbs=8000.0):
     return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -185,8 +208,142 @@ def main():
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-telemetry", action="store_true", help="no rocm-smi sampling during the timed region (always off under a profiler)")
+    ap.add_argument("--no-exchange", action="store_true", help="skip the weight-update / trajectory-gather exercise after the timed region")
+    ap.add_argument("--no-tower-parity", action="store_true", help="skip the bf16-against-fp32 tower comparison after the timed region")
+    ap.add_argument("--exchange-games", type=int, default=1024, help="synthetic finished games (400 plies each) every rank packs and sends")
+    return ap.parse_args(argv)
 
+
+def launch_ranks(args, argv, script=None):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks of this script, one per GPU.  This process never
+    touches the GPU (no torch.cuda call, no engine): it only starts children, and a child is a fresh interpreter that finds
+    RANK set and runs the bench itself.  Rank 0 inherits stdout, so its one JSON line is this command's output; the other
+    ranks' stdout goes to stderr.  Returns the first non-zero exit status of any rank (after ending the others), else 0."""
+    import socket
+    import subprocess
+    n = args.gpus
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    status = 0
+    live = set(range(n))
+    while live:
+        for r in list(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 128 - rc
+                print("bench.py: rank %d exited with status %d; ending the other ranks" % (r, rc), file=sys.stderr)
+                for q in live:           # they would wait for the lost rank in the next collective
+                    procs[q].terminate()
+        time.sleep(0.2)
+    return status
+
+
+def exchange_exercise(eng, parallel, torch, dist, rank, world, dev, blob_t, O, n_games, backend):
+    """The two exchanges of a multi-GPU self-play job, once each, outside the timed region (a generation's worth):
+    the model update (rank 0's folded weights to every rank's tower, device memory to device memory) and the trajectory
+    gather (every rank's finished games, packed sparse, to rank 0 where the replay buffer lives).  The games are synthetic
+    and shaped like finished ones: 400 plies, a few dozen visited children per ply."""
+    out = {"backend": backend if dist is not None else "none (one rank)", "world": world}
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # 1. model update
+    sync()
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        parallel.update_weights(eng, blob_t if rank == 0 else None, dist, dev)
+        sync()
+        times.append((time.perf_counter() - t0) * 1e3)
+    out["weights"] = {"bytes": int(eng.tower_blob_floats()) * 4, "ms_first": times[0], "ms": times[1],
+                      "path": "broadcast of a GPU tensor, then az_tower_load_weights_dev (no host copy)"}
+    # 2. trajectories
+    plies = 400
+    rows = n_games * plies
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    visits = torch.zeros((rows, O), dtype=torch.int32, device=dev)
+    mask = torch.rand((rows, O), device=dev, generator=g) < (40.0 / O)
+    visits[mask] = torch.randint(1, 200, (int(mask.sum()),), device=dev, generator=g, dtype=torch.int32)
+    del mask
+    moves = torch.randint(0, O, (rows,), device=dev, generator=g, dtype=torch.int32).to(torch.int16)
+    sync()
+    t0 = time.perf_counter()
+    packed = parallel.pack_sparse(moves, visits, [plies] * n_games, [1] * n_games)
+    torch.cuda.synchronize()
+    t_pack = (time.perf_counter() - t0) * 1e3
+    dense = rows * (O * 4 + 2)
+    del visits
+    sync()
+    t0 = time.perf_counter()
+    got = parallel.gather_packed(packed, dist, dst=0)
+    sync()
+    t_gather = (time.perf_counter() - t0) * 1e3
+    ok = True
+    if rank == 0:
+        ok = len(got) == world
+        for b in got:
+            head = b[:16].view(torch.int32).tolist()
+            ok = ok and head[0] == parallel._MAGIC and head[1] == n_games and head[2] == rows and b.device.type == "cuda"
+    recv = sum(parallel.packed_nbytes(b) for b in got[1:]) if rank == 0 else 0
+    out["trajectories"] = {"games_per_rank": n_games, "plies_per_game": plies, "dense_bytes_per_rank": dense,
+                           "packed_bytes_per_rank": parallel.packed_nbytes(packed), "pack_ms": t_pack, "gather_ms": t_gather,
+                           "bytes_into_rank0": recv, "gather_gb_per_s": (recv / (t_gather * 1e-3) / 1e9) if t_gather > 0 and recv else None,
+                           "received_ok": bool(ok), "wire": "uint8 view of the packed int16 tensor, point to point, 64 MiB chunks"}
+    return out
+
+
+def tower_parity(torch, np, eng, H, O, blocks, channels, planes, device):
+    """bf16 tower against the fp32 tower of the same library on the same boards and weights: the bench's architecture with
+    batch-norm statistics calibrated on data (as a trained network's are; the timed run itself uses untouched statistics,
+    with which a random 20-block tower has logits of magnitude 50 and no tolerance means anything).  96 boards, so the
+    bf16 side runs the tiled kernels of large batches."""
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.network.model import calibrate_bn, fold_to_blob, random_net
+    B = min(96, planes.shape[0])
+    x = np.ascontiguousarray(planes[:B])
+    net = random_net(H, H, O, blocks, channels, seed=0)
+    calibrate_bn(net, torch.from_numpy(x[:4].astype(np.float32)))
+    blob = fold_to_blob(net)
+    res = {}
+    for dt in ("bf16", "fp32"):
+        e = Engine(eng.game, H, H, eng.cfg.k, n_slots=B, num_blocks=blocks, channels=channels, tower_dtype=dt, device=device)
+        e.tower_load(blob)
+        res[dt] = e.tower_forward(x)
+        kern = e.tower_conv_kernel() if dt == "bf16" else None
+        if dt == "bf16":
+            res["kernel"] = kern
+        e.close()
+    dp = np.abs(res["bf16"][0] - res["fp32"][0]); dv = np.abs(res["bf16"][1] - res["fp32"][1])
+    out = {"what": "bf16 tower against the fp32 tower (same library, same weights, batch-norm statistics calibrated) on %d leaf boards of this run" % B,
+           "kernel": res["kernel"], "priors_max_abs_diff": float(dp.max()), "value_max_abs_diff": float(dv.max()),
+           "value_mean_abs_diff": float(dv.mean()), "bound_bf16": 1e-2, "priors_within_bound": bool(dp.max() <= 1e-2),
+           "value_within_bound": bool(dv.max() <= 1e-2)}
+    try:
+        with open(os.path.join(ROOT, "profiles", "round3_bf16_search_effect.json")) as f:
+            out["search_effect"] = json.load(f)
+    except (OSError, ValueError):
+        out["search_effect"] = None
+    return out
+
+
+def main(args):
     import numpy as np
     import torch
 
@@ -200,13 +357,16 @@ def main():
     if "AZ_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["AZ_BENCH_DEVICE"])
     backend = os.environ.get("AZ_BENCH_DIST_BACKEND", "nccl")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants GPU %d but only %d are visible (--gpus %d)" % (rank, local_rank, torch.cuda.device_count(), args.gpus))
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or "RANK" in os.environ:  # under torchrun the RCCL path is taken even with one rank
+    if world > 1 or "RANK" in os.environ:  # under a launcher the RCCL path is taken even with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
@@ -229,12 +389,11 @@ def main():
     eng = Engine(args.game, H, H, args.k, n_slots=args.games, max_playout=args.sims, transform_types=8, dirichlet_before=30,
                  max_turn=400, d_alpha=0.03, d_epsilon=0.25, seed=1000 + rank, record_trajectories=True,
                  num_blocks=args.blocks, channels=args.channels, tower_dtype=args.dtype, device=local_rank)
-    # weights: rank 0 builds them, every rank receives them over RCCL (model update path)
-    blob = None
+    # weights: rank 0 builds them, every rank receives them over RCCL and loads them from GPU memory (model update path)
+    blob_t = None
     if rank == 0:
-        blob = fold_to_blob(random_net(H, H, O, args.blocks, args.channels, seed=0))
-    blob = parallel.broadcast_weights(blob, eng.tower_blob_floats(), dist, torch.device("cuda", local_rank))
-    eng.tower_load(blob)
+        blob_t = torch.from_numpy(fold_to_blob(random_net(H, H, O, args.blocks, args.channels, seed=0))).to(dev)
+    parallel.update_weights(eng, blob_t, dist, dev)
     eng.selfplay_start()
     rps = args.rounds_per_step if args.rounds_per_step > 0 else -(-(args.sims + 1) // 20)
     rounds, warm_rounds = args.steps * rps, args.warmup * rps
@@ -251,7 +410,8 @@ def main():
     eng.selfplay_run(warm_rounds)
     eng.counters_reset()
     barrier()
-    sampler = PowerSampler(local_rank) if rank == 0 else None
+    sample = rank == 0 and not args.no_telemetry and not PowerSampler.under_profiler()
+    sampler = PowerSampler(local_rank) if sample else None
     if sampler:
         sampler.start()
     t0 = time.perf_counter()
@@ -277,12 +437,30 @@ def main():
     whole_searches = total_moves >= total_games
     moves_per_s = total_moves / dt if whole_searches else steady_moves_per_s
 
+    # ---- after the timed region: the exchanges of a multi-GPU job, and the tower's bf16 error on this run's boards
+    exchange = None
+    if not args.no_exchange:
+        try:
+            exchange = exchange_exercise(eng, parallel, torch, dist, rank, world, dev, blob_t, O,
+                                         max(1, min(args.exchange_games, args.games)), backend)
+        except Exception as e:  # noqa: BLE001 - the measured line must survive a failed exercise, and say so
+            exchange = {"error": "%s: %s" % (type(e).__name__, e)}
+    parity = None
+    if rank == 0 and args.dtype == "bf16" and not args.no_tower_parity:
+        try:
+            planes, valid = eng.leaf_batch()
+            parity = tower_parity(torch, np, eng, H, O, args.blocks, args.channels, planes[np.flatnonzero(valid)], local_rank)
+        except Exception as e:  # noqa: BLE001
+            parity = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if rank == 0:
         conv_ms = c["conv_ms"] / max(c["conv_launches"], 1)
         achieved = c["conv_flops_per_launch"] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         # the tower takes a large batch through its layers in groups of boards: a launch covers one group
         boards_per_launch = c["conv_flops_per_launch"] / (2.0 * H * H * 9.0 * args.channels * args.channels)
         traffic, traffic_src = measured_traffic(boards_per_launch, H, args.channels) if args.dtype == "bf16" and boards_per_launch > 0 else (None, None)
+        # the bf16 kernels run on the matrix cores; the fp32 tower (parity mode) is a vector-ALU kernel
+        peak, bound = (MFMA_PEAK_TFLOPS_BF16, "mfma") if args.dtype == "bf16" else (VALU_PEAK_TFLOPS_FP32, "valu")
         out = {
             "metric": "self-play moves/sec + MCTS sims/sec (node), Go 19x19 800 sims, 1/2/4/8 GPUs",
             "value": moves_per_s, "unit": "moves/s", "sims_per_sec": sims_per_s,
@@ -313,9 +491,9 @@ def main():
                                             c["peak_tree_blocks"] / max(c["tree_block_cap"], 1))},
             "tree_stats_per_sim": {"levels": c["levels"] / max(c["evals"], 1), "children_scanned": c["children_scanned"] / max(c["evals"], 1)},
             "roofline": {
-                "bound": "mfma", "kernel": "k_conv3x3_c256_bf16_duo (3x3 256->256 implicit GEMM, bf16 MFMA 16x16x32, two 4-wave workgroups per CU)",
-                "achieved": achieved, "peak": MFMA_PEAK_TFLOPS_BF16, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_PEAK_TFLOPS_BF16, "traffic": traffic, "traffic_source": traffic_src,
+                "bound": bound, "kernel": eng.tower_conv_kernel(),
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": conv_ms, "launches": c["conv_launches"], "flops_per_launch": c["conv_flops_per_launch"],
                 "boards_per_launch": boards_per_launch,
                 "timing": "HIP events on the launch stream around every conv launch of every %d-th round of the timed "
@@ -325,6 +503,8 @@ def main():
             "hbm_kernels": hbm_kernels(c, H * H, O, rounds),
             "gpu_telemetry": gpu_telemetry,
             "tower_tflops_end_to_end": (c["tower_evals"] * eng.tower_flops_per_eval()) / (c["tower_ms"] * 1e-3) / 1e12 if c["tower_ms"] > 0 else 0.0,
+            "exchange": exchange,
+            "tower_parity": parity,
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only; at N>1 the other ranks would idle behind it
             out["cpu_baseline"] = cpu_baseline(args.game, H, args.k, args.blocks, args.channels, args.sims)
@@ -347,7 +527,10 @@ def _emit(line):
 
 
 if __name__ == "__main__":
+    _args = parse_args()
+    if _args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(_args, sys.argv[1:]))
     sys.stdout.flush()
     _REAL_STDOUT = os.dup(1)
     os.dup2(2, 1)
-    main()
+    main(_args)

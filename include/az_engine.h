@@ -49,6 +49,9 @@ extern "C" {
 typedef struct az_engine az_engine;
 
 typedef struct az_config {
+    uint32_t struct_size;      /* sizeof(az_config) as the caller sees it.  az_engine_create refuses any other value than the
+                                  library's own, so a binding written against another version of this header fails at the
+                                  first call instead of being read past its end.  az_abi_sizes reports the library's sizes. */
     int32_t game;              /* AZ_GO / AZ_REVERSI / AZ_MNK  (config key env_path) */
     int32_t board_height, board_width, k;
     int32_t n_slots;           /* concurrent games on this GPU */
@@ -85,6 +88,14 @@ typedef struct az_config {
                                   points and inside the search, as the reference's GTP games run (interface/gtp_wrapper.py:88);
                                   self-play runs without it (game/gameplay.py:22).  A slot then keeps its move list and the
                                   hash of every position, up to max(max_turn + 2, 1024) + max_depth moves */
+    double c_punt;             /* exploration constant of the selection score, the module global c_punt of search/mcts.py:9 used at
+                                  :88; 0 = the reference's 5.0.  az_search_set_c_punt changes it between searches */
+    /* Switches that only serve A/B timing and tests; 0 everywhere is the production setting. */
+    int32_t tower_no_graphs;   /* 1: small-batch forwards are launched kernel by kernel, never replayed as captured HIP graphs */
+    int32_t tower_no_duo;      /* 1: the one-workgroup slab convolution also where the two-workgroups-per-CU kernel applies */
+    int32_t tower_group_boards;/* boards per group when a large batch goes through the tower in groups: 0 = automatic,
+                                  -1 = never (whole batch layer by layer), N = groups of N boards */
+    int32_t match_serial_towers; /* 1: the two towers of a two-network match run one after the other on one stream */
 } az_config;
 
 /* Fixed-layout copy of one game state (attributes of env/*.py GameState). */
@@ -124,6 +135,10 @@ typedef struct az_counters {
 /* Replaces constructing GameState/Player/Game objects one process per game
  * (AlphaZero/train/parallel/selfplay.py:71-108). */
 az_engine *az_engine_create(const az_config *cfg);
+/* sizeof of the three structs of this header as the library was compiled: out[0] = az_config, out[1] = az_state_blob,
+ * out[2] = az_counters.  A binding in another language checks its own struct definitions against these before the first
+ * az_engine_create (no handle needed).  No counterpart in the reference, which has no FFI. */
+void az_abi_sizes(int32_t out[3]);
 void az_engine_destroy(az_engine *h);
 const char *az_last_error(az_engine *h);       /* h may be NULL (creation errors) */
 int az_engine_dims(az_engine *h, int32_t *n_slots, int32_t *cells, int32_t *actions);
@@ -188,6 +203,8 @@ int az_search_advance(az_engine *h, const int32_t *slots, int32_t n, const int32
 int az_search_grow_trees(az_engine *h, int32_t edge_cap, int32_t block_cap);
 /* nodes (edges) and expanded nodes currently held by a tree */
 int az_search_tree_size(az_engine *h, int32_t slot, int32_t side, int32_t *edges, int32_t *blocks);
+/* Assigning the module global c_punt of search/mcts.py:9: the value every later selection step uses (c_punt > 0). */
+int az_search_set_c_punt(az_engine *h, double c_punt);
 
 /* ---- self-play machine (game/gameplay.py Game.start over all slots) ---- */
 int az_selfplay_start(az_engine *h);            /* reset every slot and arm player_1's first search */
@@ -235,6 +252,12 @@ int az_rng_cursor(az_engine *h, int32_t slot, int64_t *i_tids, int64_t *i_etas, 
 size_t az_tower_blob_floats(az_engine *h);      /* float32 count of the folded-weight blob */
 /* folded float32 weights, layout documented in alphazero_amd/network/model.py */
 int az_tower_load_weights(az_engine *h, const float *blob, size_t n_floats);
+/* The same blob already in this GPU's memory (e.g. the tensor an RCCL broadcast delivered): padding, conversion to the
+ * compute type and the copies into the tower's weight arrays run on the GPU, nothing passes through host memory.  net = 0 / 1
+ * as az_tower_load_weights_net.  The caller's writes to blob_dev must be complete (its stream synchronised); the call
+ * returns after the engine's stream has finished reading it.  Replaces saver.restore of a checkpoint path in every worker
+ * (train/parallel/selfplay.py:110-122, evaluator/nn_eval_parallel.py:100-106). */
+int az_tower_load_weights_dev(az_engine *h, int32_t net, const float *blob_dev, size_t n_floats);
 /* float64 forms of the three calls that carry W / P / priors / values, for engines created with search_f64 = 1
  * (the float32 forms return AZ_ERR_ARG on such an engine, and these on a float32 engine) */
 int az_search_step_finish_f64(az_engine *h, const double *priors, const double *values);
@@ -261,6 +284,10 @@ int az_tower_forward(az_engine *h, const int8_t *planes, int32_t B, float *out_p
  * engine's stream has finished, so the outputs can be read from any stream */
 int az_tower_forward_dev(az_engine *h, const int8_t *planes_dev, int32_t B, float *out_p_dev, float *out_v_dev);
 double az_tower_flops_per_eval(az_engine *h);
+/* Name (as a profiler's kernel trace shows it) and a short description of the convolution kernel that the residual layers of a
+ * self-play round run with on this engine - it depends on the tower's type and width, the board and the slot count.
+ * Measurement only; the string lives as long as the library. */
+const char *az_tower_conv_kernel(az_engine *h);
 /* Per-launch timing of the residual tower's convolutions inside az_selfplay_run: HIP events on the launch stream
  * around every such launch, accumulated in az_counters.conv_ms / conv_launches (measurement only).
  * on=0: off.  on=1: every round (the host then waits for each round, and every round runs the full batch).

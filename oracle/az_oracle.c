@@ -537,7 +537,10 @@ struct OzTree {
     double d_alpha, d_epsilon;
 };
 
-static const oz_real C_PUNT = (oz_real)5.0; /* mcts.py:9 */
+/* mcts.py:9: a module global, so a caller may assign it; oz_set_c_punt is that assignment (tests only change it to
+ * replay fixtures the reference recorded with another value) */
+static double g_c_punt = 5.0;
+void oz_set_c_punt(double c) { g_c_punt = c; }
 
 static int tree_alloc(OzTree *t, int n)
 {
@@ -578,7 +581,7 @@ int64_t oz_tree_num_nodes(const OzTree *t) { return t->used; }
 static oz_real sel_value(const OzTree *t, const OzNode *c)
 {
     const OzNode *par = &t->nodes[c->parent];
-    oz_real u = C_PUNT * c->p;
+    oz_real u = (oz_real)g_c_punt * c->p;
     u = u * (oz_real)sqrt((double)par->n);
     u = u / (oz_real)(1.0 + (double)c->n);
     oz_real q = c->n == 0 ? (oz_real)0.0 : c->w / (oz_real)c->n;

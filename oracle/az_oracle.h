@@ -98,6 +98,7 @@ typedef struct {
 
 typedef struct OzTree OzTree;
 OzTree *oz_tree_new(int O, int transform_types, double d_alpha, double d_epsilon);
+void oz_set_c_punt(double c_punt);   /* the module global c_punt, mcts.py:9 (default 5.0) */
 void oz_tree_free(OzTree *t);
 /* MCTSearch._calc_move */
 int oz_tree_search(OzTree *t, const OzState *s, int max_playout, int dirichlet,

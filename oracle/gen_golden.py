@@ -320,7 +320,7 @@ def search_trace(name, game, H, W, k, transform_types, max_playout, dirichlet_be
     out = dict(
         name=name, game=game, H=H, W=W, k=k or 0, O=O, transform_types=transform_types,
         max_playout=max_playout, dirichlet_before=dirichlet_before, max_turn=max_turn,
-        d_alpha=cfg["d_alpha"], d_epsilon=cfg["d_epsilon"], ply_limit=ply_limit,
+        d_alpha=cfg["d_alpha"], d_epsilon=cfg["d_epsilon"], ply_limit=ply_limit, c_punt=float(mcts.c_punt),
         tids=np.array(streams.tids, np.int32), etas=np.array(streams.etas, np.float64),
         unis=np.array(streams.unis, np.float64),
         n_children=np.array([r["n"] for r in recs], np.int32),
@@ -414,6 +414,19 @@ def main_match():
     mnk.game_config.update(board_height=6, board_width=5, k=4)
 
 
+def main_cpunt():
+    """The exploration constant is a module global of the reference (search/mcts.py:9) that a user may assign: traces
+    recorded with two other values pin that the engine's c_punt means the same thing."""
+    old = mcts.c_punt
+    try:
+        mcts.c_punt = 1.25
+        save("search_go9_cpunt125", search_trace("go9c", "go", 9, 9, None, 8, 48, 30, 400, 91, 8))
+        mcts.c_punt = 9.5
+        save("search_reversi_cpunt95", search_trace("revc", "reversi", 8, 8, None, 8, 40, 30, 400, 92, 12))
+    finally:
+        mcts.c_punt = old
+
+
 def main_superko():
     """Positional superko (enforce_superko=True, what the GTP front end plays with: interface/gtp_wrapper.py:88): long random
     games on small boards, where captured stones are replayed often enough for the rule to bite."""
@@ -438,6 +451,8 @@ def main():
         return main_match()
     if "--only-shapes" in sys.argv:
         return main_shapes()
+    if "--only-cpunt" in sys.argv:
+        return main_cpunt()
     # ---- transforms: label tables of ReverseTransformer and forward board maps
     tabs = {}
     for n in (3, 5, 7, 8, 9, 19):
@@ -511,6 +526,7 @@ def main():
     main64()
     main_match()
     main_superko()
+    main_cpunt()
 
 
 if __name__ == "__main__":

@@ -113,10 +113,17 @@ def lib(real64=False):
                                       C.POINTER(OzRng), C.POINTER(OzTrajectory), C.c_int]
         L.oz_tree_search_k.argtypes = [C.c_void_p, SP, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
                                        C.POINTER(OzRng)]
+        L.oz_set_c_punt.argtypes = [C.c_double]
+        L.oz_set_c_punt.restype = None
         L.oz_gamma_small_alpha.restype = C.c_double
         L.oz_gamma_small_alpha.argtypes = [C.c_double, C.POINTER(C.c_uint64)]
         _libs[real64] = L
     return _libs[real64]
+
+
+def set_c_punt(c_punt, real64=False):
+    """Assign the module global c_punt (search/mcts.py:9) of the oracle build in question."""
+    lib(real64).oz_set_c_punt(float(c_punt))
 
 
 def fn_ptr(name, real64=False):

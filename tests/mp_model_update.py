@@ -26,11 +26,13 @@ def main():
     eng = Engine("go", H, H, n_slots=G, max_playout=P, transform_types=8, max_turn=20, seed=100 + rank, record_trajectories=True, **kw)
     blob_a = fold_to_blob(random_net(H, H, O, NB, C, seed=1, perturb_bn=True)) if rank == 0 else None
     blob_b = fold_to_blob(random_net(H, H, O, NB, C, seed=2, perturb_bn=True)) if rank == 0 else None
-    blob_a = parallel.update_weights(eng, blob_a, dist)
+    dev = torch.device("cuda", 0)
+    # device path end to end: the broadcast's result is loaded into the tower from GPU memory (az_tower_load_weights_dev)
+    blob_a = parallel.update_weights(eng, blob_a, dist, dev).cpu().numpy()
     eng.selfplay_start()
     eng.selfplay_run(3 * (P + 1) + 4)                      # three plies in, mid-search
     plies0, done0 = eng.selfplay_status()
-    blob_b = parallel.update_weights(eng, blob_b, dist)    # the model update arrives while every slot is mid-game
+    blob_b = parallel.update_weights(eng, blob_b, dist, dev).cpu().numpy()   # the model update arrives while every slot is mid-game
     eng.selfplay_run(1)
     planes, _ = eng.leaf_batch()
     p, v = eng.leaf_outputs()
@@ -53,7 +55,7 @@ def main():
     host = eng.trajectory_pop_many(fin, plies[fin])
     same_local = len(local) == len(host) and all(np.array_equal(a["moves"], b["moves"]) and np.array_equal(a["visits"], b["visits"]) and
                                                  a["winner"] == b["winner"] for a, b in zip(local, host))
-    blobs = parallel.gather_packed(packed.cpu(), dist, dst=0)            # gloo moves host tensors; RCCL would take `packed` as it is
+    blobs = parallel.gather_packed(packed, dist, dst=0)   # device tensor in, device tensors out (gloo stages through the host, RCCL does not)
     got = [t for b in blobs for t in parallel.unpack_trajectories(b, O)]
     digest = [int(t["visits"].sum()) * 31 + int(t["moves"].astype(np.int64).sum()) for t in local]
     all_digests = [None] * world

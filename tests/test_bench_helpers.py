@@ -47,3 +47,68 @@ def test_gpu_telemetry_parser_reads_rocm_smi_json():
     assert rec["socket_power_w"] == 1355.0 and rec["hotspot_c"] == 58.0 and rec["memory_controller_activity_pct"] == 7.0
     assert rec["power_limit_residency"] == 644259.0 and rec["thermal_residency"] == 0.0
     assert "gfxclk_mhz" not in rec                    # a list with an unreadable entry is dropped, not half-read
+
+
+# ---- `python bench.py --gpus N` as its own launcher (no GPU needed: the ranks here are a stand-in script) -----------------
+
+_STUB = """
+import json, os, sys, time
+r = int(os.environ["RANK"])
+if os.environ.get("STUB_FAIL_RANK") == str(r):
+    sys.exit(3)
+if "STUB_FAIL_RANK" in os.environ:
+    time.sleep(60)          # a healthy rank that would wait for the lost one in a collective
+print(json.dumps({k: os.environ[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")} | {"argv": sys.argv[1:]}))
+"""
+
+
+def _run_launcher(tmp_path, n, extra_env=None):
+    import subprocess
+    import sys
+    stub = tmp_path / "rank_stub.py"
+    stub.write_text(_STUB)
+    code = ("import importlib.util, sys; spec = importlib.util.spec_from_file_location('bench', %r); b = importlib.util.module_from_spec(spec); "
+            "spec.loader.exec_module(b); a = b.parse_args(['--gpus', '%d', '--steps', '3']); sys.exit(b.launch_ranks(a, ['--gpus', '%d', '--steps', '3'], script=%r))"
+            % (os.path.join(ROOT, "bench.py"), n, n, str(stub)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+
+
+def test_plain_command_with_gpus_n_starts_n_ranks(tmp_path):
+    import json
+    r = _run_launcher(tmp_path, 3)
+    assert r.returncode == 0, r.stderr
+    out = [json.loads(x) for x in r.stdout.strip().splitlines()]
+    err = [json.loads(x) for x in r.stderr.strip().splitlines() if x.startswith("{")]
+    assert len(out) == 1 and out[0]["RANK"] == "0"                       # only rank 0 owns stdout (the one JSON line)
+    assert sorted(e["RANK"] for e in err) == ["1", "2"]
+    for e in out + err:
+        assert e["WORLD_SIZE"] == "3" and e["LOCAL_RANK"] == e["RANK"] and e["MASTER_ADDR"] == "127.0.0.1"
+        assert e["MASTER_PORT"] == out[0]["MASTER_PORT"] and e["argv"] == ["--gpus", "3", "--steps", "3"]
+
+
+def test_launcher_reports_a_failed_rank_and_ends_the_others(tmp_path):
+    import time
+    t0 = time.time()
+    r = _run_launcher(tmp_path, 2, {"STUB_FAIL_RANK": "1"})
+    assert r.returncode == 3 and "rank 1 exited with status 3" in r.stderr
+    assert time.time() - t0 < 30                                         # rank 0's 60 s wait was cut short
+
+
+def test_the_launcher_is_taken_only_without_a_rank_in_the_environment():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'if _args.gpus > 1 and "RANK" not in os.environ:' in src      # under torchrun the ranks exist already
+    # the launcher itself must not initialise the GPU: nothing of torch or the engine is imported before it runs
+    head = src[:src.index("def main(args):")]
+    assert "import torch" not in head.split("def launch_ranks")[1].split("def exchange_exercise")[0]
+
+
+def test_telemetry_is_off_under_a_profiler(monkeypatch):
+    for k in list(os.environ):
+        if k.startswith(("ROCP", "HSA_TOOLS")):
+            monkeypatch.delenv(k)
+    monkeypatch.delenv("LD_PRELOAD", raising=False)
+    assert not bench.PowerSampler.under_profiler()
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    assert bench.PowerSampler.under_profiler()

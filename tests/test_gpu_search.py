@@ -17,7 +17,7 @@ def _engine_for(g, n_slots=1, record=False, **kw):
                   max_playout=int(g["max_playout"]), transform_types=int(g["transform_types"]),
                   dirichlet_before=int(g["dirichlet_before"]), max_turn=int(g["max_turn"]),
                   d_alpha=float(g["d_alpha"]), d_epsilon=float(g["d_epsilon"]), rng_replay=True,
-                  record_trajectories=record, **kw)
+                  record_trajectories=record, c_punt=float(g["c_punt"]) if "c_punt" in g else 5.0, **kw)
 
 
 def _evaluate(planes, O, evaluator):

@@ -302,3 +302,34 @@ def test_tower_forward_on_device_tensors():
     pt, vt = eng.tower_forward_torch(torch.from_numpy(x).cuda())
     assert pt.is_cuda and np.array_equal(pt.cpu().numpy(), p) and np.array_equal(vt.cpu().numpy(), v)
     eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_weights_loaded_from_device_memory_equal_the_host_load(dtype):
+    """az_tower_load_weights_dev (padding, bf16 conversion and copies done by kernels on a blob in GPU memory, what the RCCL
+    broadcast of a model update delivers) leaves the tower with the same weights as az_tower_load_weights from a host
+    array: same outputs bit for bit, for both networks of an engine; a blob of the wrong size or a host pointer is refused."""
+    from alphazero_amd.engine import Engine, EngineError
+    from alphazero_amd.network.model import fold_to_blob, random_net
+    H, NB, C = 9, 3, 256
+    O = H * H + 1
+    blobs = [fold_to_blob(random_net(H, H, O, NB, C, seed=s, perturb_bn=True)) for s in (11, 12)]
+    blobs[1][7] = np.float32(np.nan)                   # the two conversions must agree on a NaN's bit pattern as well
+    x = _boards(40, H, H, seed=3)
+    host = Engine("go", H, H, n_slots=40, num_blocks=NB, channels=C, tower_dtype=dtype)
+    devi = Engine("go", H, H, n_slots=40, num_blocks=NB, channels=C, tower_dtype=dtype)
+    host.tower_load(blobs[0])
+    devi.tower_load_torch(torch.from_numpy(blobs[0]).cuda())
+    p0, v0 = host.tower_forward(x)
+    p1, v1 = devi.tower_forward(x)
+    assert np.array_equal(p0, p1) and np.array_equal(v0, v1)
+    # a second load replaces the first (a model update), and network 1 of a match takes the same path
+    host.tower_load(blobs[1]); devi.tower_load_torch(torch.from_numpy(blobs[1]).cuda())
+    p0, v0 = host.tower_forward(x); p1, v1 = devi.tower_forward(x)
+    assert np.array_equal(p0.view(np.uint32), p1.view(np.uint32)) and np.array_equal(v0.view(np.uint32), v1.view(np.uint32))
+    devi.tower_load_torch(torch.from_numpy(blobs[0]).cuda(), net=1)
+    with pytest.raises(EngineError):
+        devi._ck(devi._L.az_tower_load_weights_dev(devi._h, 0, torch.zeros(10, device="cuda").data_ptr(), 10))
+    with pytest.raises(EngineError):
+        devi._ck(devi._L.az_tower_load_weights_dev(devi._h, 0, blobs[0].ctypes.data, blobs[0].size))   # a host pointer
+    host.close(); devi.close()

@@ -94,6 +94,19 @@ def _replay_search(g):
     trees = [oz.Tree(O, int(g["transform_types"]), float(g["d_alpha"]), float(g["d_epsilon"]), real64) for _ in range(2)]
     cur = 0
     evals = 0
+    oz.set_c_punt(float(g["c_punt"]) if "c_punt" in g else 5.0, real64)   # (older fixtures: the reference's default)
+    try:
+        _replay_plies(g, st, trees, rng, ev, bits)
+    finally:
+        oz.set_c_punt(5.0, real64)
+    assert not rng.r.underflow
+    assert np.array_equal(st.board(), g["final_board"])
+    return st
+
+
+def _replay_plies(g, st, trees, rng, ev, bits):
+    cur = 0
+    evals = 0
     for ply in range(len(g["moves"])):
         assert not (st.s.is_end or st.s.turns > int(g["max_turn"]))
         assert np.array_equal(st.board(), g["boards"][ply])
@@ -117,9 +130,6 @@ def _replay_search(g):
         trees[0].update_with_move(mv)
         trees[1].update_with_move(mv)
         cur ^= 1
-    assert not rng.r.underflow
-    assert np.array_equal(st.board(), g["final_board"])
-    return st
 
 
 @pytest.mark.parametrize("name", golden_names("search_") + golden_names("search64_"))

@@ -76,7 +76,7 @@ def _work(rank, world, port, q):
     packed = parallel.pack_trajectories(mine, O)
     dense = sum(t["visits"].nbytes + t["moves"].nbytes for t in mine)
     res["ratio"] = parallel.packed_nbytes(packed) / max(dense, 1)
-    blobs = parallel.gather_packed(packed, dist, dst=0, chunk_elems=50000)
+    blobs = parallel.gather_packed(packed, dist, dst=0, chunk_bytes=100001)   # odd on purpose: chunks stay whole int16s
     got = [t for b in blobs for t in parallel.unpack_trajectories(b, O)]
     exp = [t for r in range(world) for t in _games(r, O, SHAPES[r], 900)] if rank == 0 else []
     res["gather"] = _same(got, exp)
@@ -90,6 +90,7 @@ def _work(rank, world, port, q):
     eng = _StubEngine(64)
     new = np.linspace(-1, 1, 64).astype(np.float32) if rank == 0 else None
     parallel.update_weights(eng, new, dist)
+    res["wire_dtype"] = str(parallel.wire_bytes(packed).dtype)     # what send / recv see: RCCL has no int16
     res["update"] = len(eng.loaded) == 1 and eng.loaded[0][0] == 0 and bool(np.array_equal(eng.loaded[0][1], np.linspace(-1, 1, 64).astype(np.float32)))
     q.put((rank, res))
     dist.barrier()
@@ -110,6 +111,7 @@ def test_broadcast_and_gather_world2():
         r = res[rank]
         assert "error" not in r, r["error"]
         assert r["weights"] and r["gather"] and r["wide"] and r["update"] and r["empty"] == 0, (rank, r)
+        assert r["wire_dtype"] == "torch.uint8"
         assert r["n_got"] == (7 if rank == 0 else 0)          # only rank 0, the replay buffer's home, receives
         assert r["ratio"] < 0.25                              # packed rows against dense int32 rows
 

@@ -43,7 +43,13 @@ def test_static_pop_equals_pop_many_twice(game, H, extra, G, max_turn):
     _same(got, want)
     second = np.array([G - 1, 3, 10, 7, 1])    # smaller, other slots, not sorted: the array still holds the first call's rows
     want2 = eng.trajectory_pop_many(second, plies[second], restart=False)
+    import torch
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info(0)[0]
     got2 = eng.trajectory_pop_many(second, plies[second], restart=False, static=True)
+    # "allocates nothing": the GPU's free memory is what it was before the call (the allocating call above grew its staging
+    # buffer on its first use; this one has none to grow)
+    assert torch.cuda.mem_get_info(0)[0] == free_before
     _same(got2, want2)
     # restart through the static call re-arms the slots like the allocating call does
     eng.trajectory_pop_many(second, plies[second], restart=True, static=True)

@@ -1,3 +1,6 @@
+// HARNESS COPY (tools/conv_bench.hip only; not part of the library): alphazero_amd/csrc/az_conv_kernels.h with the switches
+// the timing studies were made with - ABL_NOBAR / ABL_NOWAIT / ABL_NODMA / ABL_NOREAD / ABL_NOMFMA (parts of the K loop
+// removed), MFMA_BUILTIN, ONE_BAR, SLAB_NT, NO_XCD_REMAP (variants), STAMP (shader-clock stamps).
 // Convolution kernels of the tower (device code only); included by az_tower.hip and by tools/conv_bench.hip.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -62,8 +65,8 @@ __global__ void k_planes_to_nhwc(const int8_t *planes, T *X0, int H, int W, cons
 // ---------------------------------------------------------------------------
 template <int KC, bool RESID>
 __global__ __launch_bounds__(256) void k_conv3x3_bf16(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
-                                                      const float *__restrict__ bias, const bf16_t *R,
-                                                      bf16_t *Y, int M, int HW, int Wd, int PP, int CIN, int COUT)
+                                                      const float *__restrict__ bias, const bf16_t *__restrict__ R,
+                                                      bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP, int CIN, int COUT)
 {
     constexpr int LDK = KC + 8;          // +16 B per row: conflict-free 16-byte fragment reads
     constexpr int CPR = KC / 8;          // 16-byte chunks per row
@@ -178,11 +181,17 @@ __device__ __forceinline__ void glds16(const bf16_t *g, unsigned char *l)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
+// the same with the non-temporal cache policy (bytes read once: an activation slab)
+__device__ __forceinline__ void glds16_nt(const bf16_t *g, unsigned char *l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)l, 16, 0, 2);
+}
 
 template <bool RESID>
 __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
-                                                           const float *__restrict__ bias, const bf16_t *R,
-                                                           bf16_t *Y, int M, int HW, int Wd, int PP)
+                                                           const float *__restrict__ bias, const bf16_t *__restrict__ R,
+                                                           bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP)
 {
     constexpr int C = 256;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[V2_LDS_BYTES];
@@ -298,12 +307,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16(const bf16_t *__restr
 
 // bias -> bf16 -> per-wave LDS transpose -> 16-byte rows (+ residual, ReLU) -> NHWC stores.
 // All LDS reads of the K loop must be complete (barrier) before the call.
-// R and Y may be the same buffer (the tower in groups of boards writes a block's output over its residual input): every
-// output element depends on the residual at that element only, and neither pointer is declared restrict in any bf16
-// convolution kernel, so the compiler keeps each element's residual load ahead of its store.
 template <bool RESID, int NI>
 __device__ __forceinline__ void conv_epilogue(unsigned char *smem, const int *rowoff, f32x4 (&acc)[NI][8], const float *__restrict__ bias,
-                                              const bf16_t *R, bf16_t *Y, int M, int m0, int wave, int lane,
+                                              const bf16_t *__restrict__ R, bf16_t *__restrict__ Y, int M, int m0, int wave, int lane,
                                               int wr, int cbase)
 {
     constexpr int C = 256;
@@ -358,10 +364,21 @@ __device__ __forceinline__ void conv_epilogue(unsigned char *smem, const int *ro
 
 // ---------------------------------------------------------------------------
 // Raw workgroup barrier for the ping-pong schedule of the slab kernel below (no implicit waitcnt, so
-// LDS-DMA stays in flight across it).  (tools/conv_ablation_kernels.h is this file's harness copy with the ablation
-// and shader-clock-stamp switches that the timing studies were made with; nothing here is conditional.)
+// LDS-DMA stays in flight across it).  With -DSTAMP (development harness only) one workgroup records
+// the shader clock after every barrier.
 // ---------------------------------------------------------------------------
+#ifdef ABL_NOBAR
+#define AZ_S_BARRIER() do {} while (0)
+#else
+#define AZ_S_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+#ifdef STAMP
+__device__ unsigned long long g_stamps[2][512];
+#define PP_BAR() do { asm volatile("" ::: "memory"); AZ_S_BARRIER(); asm volatile("" ::: "memory"); \
+    if (blockIdx.x == 300 && (threadIdx.x & 255) == 0 && stamp_i < 512) g_stamps[threadIdx.x >> 8][stamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
 #define PP_BAR() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#endif
 
 // ---------------------------------------------------------------------------
 // Slab variant (the one the tower uses when the tile's pixel span fits): the activation operand
@@ -379,7 +396,11 @@ __device__ __forceinline__ void conv_epilogue(unsigned char *smem, const int *ro
 // ---------------------------------------------------------------------------
 #define V5_SLAB0 65536
 #define V5_LDS_BYTES (147456 + 2048)
+#ifdef ABL_NOWAIT
+template <int N> __device__ __forceinline__ void wait_vmcnt() {}
+#else
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#endif
 
 // Workgroups are handed to the 8 XCDs round-robin (workgroup i -> XCD i % 8), each XCD with its own L2.  Tiles that
 // are neighbours in memory share their halo rows, so workgroup i takes tile (i % 8) * ceil-share + i / 8: every XCD
@@ -387,8 +408,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // workgroup count).  Placement is only a matter of speed, never of correctness.
 __device__ __forceinline__ int xcd_tile(int wg, int nwg)
 {
+#ifdef NO_XCD_REMAP
+    return wg;
+#else
     const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+#endif
 }
 
 // CW = output channels per wave (64, 32 or 16): a workgroup covers 4 * CW channels of its 256 points and blockIdx.y
@@ -396,8 +421,8 @@ __device__ __forceinline__ int xcd_tile(int wg, int nwg)
 // but only its share of the weights).
 template <bool RESID, int NSP, int CIN = 256, int CW = 64>
 __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
-                                                                const float *__restrict__ bias, const bf16_t *R,
-                                                                bf16_t *Y, int M, int HW, int Wd, int PP, int npos,
+                                                                const float *__restrict__ bias, const bf16_t *__restrict__ R,
+                                                                bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP, int npos,
                                                                 const int32_t *__restrict__ cnt)
 {
     constexpr int NCC = CIN / 32, SLAB_BYTES = NSP * 128 * 64;  // NCC 32-channel input chunks; 256 output channels in all
@@ -416,6 +441,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
         if ((int)blockIdx.x >= nwg) return;
     }
     const int tile = xcd_tile(blockIdx.x, nwg);
+#ifdef STAMP
+    int stamp_i = 0;
+    // wall-clock phases (100 MHz counter) of an early and a late workgroup: entry, K loop start, K loop end, exit
+    const int ph_slot = blockIdx.x == 300 ? 0 : (blockIdx.x == 3000 ? 4 : -1);
+#define PH_STAMP(k) do { if (ph_slot >= 0 && threadIdx.x == 0) g_stamps[1][500 + ph_slot + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    PH_STAMP(0);
+#else
+#define PH_STAMP(k) do {} while (0)
+#endif
     static_assert(V5_SLAB0 + 2 * SLAB_BYTES <= 147456, "slab buffers overflow LDS");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[V5_LDS_BYTES];
     int *rowoff = reinterpret_cast<int *>(smem + 147456);
@@ -466,17 +500,30 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
     int opaque0 = 0;  // re-defined by an empty asm every chunk so that per-tap addresses are not hoisted into VGPRs
     // (cc, tap) = 32-channel chunk and filter tap of half-step h = 9*cc + tap; ring slot of its weights = h & 3
     auto issue_w = [&](int cc, int tap) {
+#ifdef ABL_NODMA
+        if (cc > 0) return;
+#endif
         const int wofs = tap * CIN + cc * 32 + opaque0;
         unsigned char *dst = wfill + ((cc + tap) & 3) * 16384;
 #pragma unroll
         for (int q = 0; q < WB; q++) glds16(Wt + woff[q] + wofs, dst + q * 1024);
     };
     auto issue_slab = [&](int cc) {
+#ifdef ABL_NODMA
+        if (cc > 1) return;
+#endif
         unsigned char *dst = smem + V5_SLAB0 + (cc & 1) * SLAB_BYTES + wave * 1024;
 #pragma unroll
+#ifdef SLAB_NT
+        for (int i = 0; i < NSP; i++) glds16_nt(X + soff[i] + cc * 32, dst + i * 8192);
+#else
         for (int i = 0; i < NSP; i++) glds16(X + soff[i] + cc * 32, dst + i * 8192);
+#endif
     };
     auto rd_frags = [&](int cc, int tap) {
+#ifdef ABL_NOREAD
+        if (cc > 0) return;
+#endif
         const int ty = tap / 3, tx = tap - ty * 3;
         const int tshift = ((ty - 1) * W2 + (tx - 1)) * 64 + opaque0;  // relative to the pixel's own row
         const unsigned char *wb = smem + ((cc + tap) & 3) * 16384 + wrdo;
@@ -490,13 +537,21 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
         }
     };
     auto mfma_rows = [&](int i0, int i1) {
+#ifdef ABL_NOMFMA
+        asm volatile("" :: "v"(wf[0]), "v"(xf[0]), "v"(wf[NI - 1]), "v"(xf[7]));
+        return;
+#endif
 #pragma unroll
         for (int i = i0; i < i1; i++)
 #pragma unroll
             for (int j = 0; j < 8; j++)
+#ifdef MFMA_BUILTIN
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+#else
                 // accumulate in place: tying the destination to the C operand keeps the register allocator from
                 // renaming the 128 accumulator registers from tap to tap (which costs spills inside the loop)
                 asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[i]), "v"(xf[j]));
+#endif
     };
     // One MFMA interval: 32 MFMAs with this wave's share of the LDS-DMA slipped in after the first rows.
     // dw = how many half-steps ahead the weights are fetched (3 for group 0, 2 for group 1, which issues
@@ -531,17 +586,26 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
         else wait_vmcnt<0>();
     };
 #define SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef ONE_BAR
+#define PP_MID() do {} while (0)
+#else
+#define PP_MID() PP_BAR()
+#endif
 
     issue_slab(0); issue_w(0, 0); issue_w(0, 1); issue_w(0, 2);
     wait_vmcnt<2 * WB>();
     PP_BAR();
+    PH_STAMP(1);
+#ifdef STAMP
+    if (blockIdx.x == 300 && threadIdx.x == 0) { g_stamps[0][500] = __builtin_amdgcn_s_memrealtime(); g_stamps[0][502] = __builtin_amdgcn_s_memtime(); }
+#endif
     if (wr == 0) {
         for (int cc = 0; cc < NCC; cc++) {
             asm volatile("" : "+s"(opaque0));
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) {
                 rd_frags(cc, tap);
-                SB(); PP_BAR(); SB();
+                SB(); PP_MID(); SB();
                 mfma_interval(cc, tap, 3, 0);
                 retire_g0(cc, tap);
                 SB(); PP_BAR(); SB();
@@ -556,7 +620,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
                 // MFMAs of the previous half-step (its fragments were read one interval ago)
                 if (tap > 0) mfma_interval(cc, tap - 1, 3, 0);
                 else if (cc > 0) mfma_interval(cc - 1, 8, 3, 0);
-                SB(); PP_BAR(); SB();
+                SB(); PP_MID(); SB();
                 rd_frags(cc, tap);
                 retire_g1(cc, tap);
                 SB(); PP_BAR(); SB();
@@ -566,12 +630,21 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
         PP_BAR();
     }
 #undef SB
+#undef PP_MID
+#ifdef STAMP
+    if (blockIdx.x == 300 && threadIdx.x == 0) { g_stamps[0][501] = __builtin_amdgcn_s_memrealtime(); g_stamps[0][503] = __builtin_amdgcn_s_memtime(); }
+#endif
+#ifndef MFMA_BUILTIN
     // the compiler does not know that the asm statements above are MFMAs, so it cannot insert the wait
     // states an MFMA result needs before a vector ALU read: cover the longest case by hand
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
     // (a register-swap epilogue without the LDS round trip measured 1-3 % slower in the self-play bench)
     __syncthreads();
+    PH_STAMP(2);
     conv_epilogue<RESID, NI>(smem, rowoff, acc, bias, R, Y, M, m0, wave, lane, wr, cout0 + wc * CW);
+    PH_STAMP(3);
+#undef PH_STAMP
 }
 
 // ---------------------------------------------------------------------------
@@ -593,7 +666,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
 template <bool RESID, int NPW = 6>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_conv3x3_c256_bf16_duo(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt, const float *__restrict__ bias,
-                             const bf16_t *R, bf16_t *Y, int M, int HW, int Wd, int PP, int npos,
+                             const bf16_t *__restrict__ R, bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP, int npos,
                              const int32_t *__restrict__ cnt)
 {
     constexpr int CIN = 256, NCC = 8, NPIECES = NPW == 6 ? 24 : 27, SLAB_BYTES = NPIECES * 1024;
@@ -609,6 +682,13 @@ void k_conv3x3_c256_bf16_duo(const bf16_t *__restrict__ X, const bf16_t *__restr
     }
     const int L = xcd_tile(blockIdx.x, nwg);
     const int tile = L >> 1, cout0 = (L & 1) * 128;
+#ifdef STAMP
+    const int ph_slot = blockIdx.x == 600 ? 0 : (blockIdx.x == 6000 ? 4 : -1);
+#define PH_STAMP(k) do { if (ph_slot >= 0 && threadIdx.x == 0) g_stamps[1][500 + ph_slot + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    PH_STAMP(0);
+#else
+#define PH_STAMP(k) do {} while (0)
+#endif
     __shared__ __attribute__((aligned(1024))) unsigned char smem[V6_LDS_BYTES];
     int *rowoff = reinterpret_cast<int *>(smem + V6_TABLES);
     int *srow = reinterpret_cast<int *>(smem + V6_TABLES + 1024);
@@ -665,6 +745,7 @@ void k_conv3x3_c256_bf16_duo(const bf16_t *__restrict__ X, const bf16_t *__restr
     };
 
     issue_slab(0); issue_w(0, 0); issue_w(0, 1);
+    PH_STAMP(1);
     for (int cc = 0; cc < NCC; cc++) {
         asm volatile("" : "+s"(opaque0));
 #pragma unroll
@@ -705,7 +786,10 @@ void k_conv3x3_c256_bf16_duo(const bf16_t *__restrict__ X, const bf16_t *__restr
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __syncthreads();
+    PH_STAMP(2);
     conv_epilogue<RESID, 4>(smem, rowoff, acc, bias, R, Y, M, m0, wave, lane, wr, cout0 + wc * 64);
+    PH_STAMP(3);
+#undef PH_STAMP
 }
 
 // largest number of padded positions (incl. the one-row-plus-one halo on both sides) that a tile of
@@ -813,8 +897,8 @@ static inline bool launch_v5_stem(const bf16_t *X, const bf16_t *Wt, const float
 // <4, 4, 3>: up to about 16 boards (fewer, larger workgroups: less operand re-reading).
 template <bool RESID, int NW, int NI, int UN>
 __global__ __launch_bounds__(64 * NW) void k_conv3x3_bf16_small(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
-                                                                      const float *__restrict__ bias, const bf16_t *R,
-                                                                      bf16_t *Y, int M, int HW, int Wd, int PP, int CIN,
+                                                                      const float *__restrict__ bias, const bf16_t *__restrict__ R,
+                                                                      bf16_t *__restrict__ Y, int M, int HW, int Wd, int PP, int CIN,
                                                                       int COUT)
 {
     __shared__ float part[NW][NI * 2][64][4];  // [wave][i*2+j][lane][r]

@@ -1,7 +1,7 @@
 // Dev harness: correctness + timing of the tower's 3x3 256->256 bf16 convolution kernels.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/conv_bench.hip -o tools/conv_bench
 //   tools/conv_bench [boards=1024] [iters=20] [variant=0] [resid=1] [check=1] [channel_split=0]
-#include "../alphazero_amd/csrc/az_conv_kernels.h"
+#include "conv_ablation_kernels.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
