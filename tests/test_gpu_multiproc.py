@@ -42,7 +42,7 @@ def test_plain_bench_command_with_two_gpus_runs_two_ranks():
     weights to every rank's tower from GPU memory, packed trajectories to rank 0 - after the timed region."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env.update(AZ_BENCH_DEVICE="0", AZ_BENCH_DIST_BACKEND="gloo")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--board", "9", "--sims", "19",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "25", "--warmup", "2", "--board", "9", "--sims", "19",
            "--blocks", "2", "--games", "96", "--exchange-games", "8", "--no-cpu-baseline", "--no-telemetry", "--no-tower-parity"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=170)
     assert r.returncode == 0, r.stderr[-3000:]
