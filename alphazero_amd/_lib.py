@@ -29,7 +29,7 @@ class AzConfig(C.Structure):
         ("tree_full_policy", C.c_int32), ("search_f64", C.c_int32), ("enforce_superko", C.c_int32),
         ("c_punt", C.c_double),
         ("tower_no_graphs", C.c_int32), ("tower_no_duo", C.c_int32), ("tower_group_boards", C.c_int32),
-        ("match_serial_towers", C.c_int32),
+        ("match_parallel_towers", C.c_int32),
     ]
 
 

@@ -5,6 +5,7 @@
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef unsigned short bf16_t;
 
 #define CIN0 32  // input planes (17) padded to one K chunk
@@ -29,9 +30,68 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
 }
 
 // ---------------------------------------------------------------------------
+// The 16-bit storage format of activations and weights is a template parameter F of every kernel below:
+//   F = 0  bfloat16 (8 significant bits, float32's exponent range)
+//   F = 1  IEEE half precision (11 significant bits, largest finite value 65504)
+// Both feed the same MFMA shape at the same rate and move the same bytes; half precision rounds 8 times finer, which is
+// what a 10- or 20-block tower needs to keep its value output within 1e-2 of float32.  Activations are clamped to the
+// format's finite range on conversion (a bf16 tower cannot overflow; a half-precision one must not turn a large
+// activation into an infinity).  The element type in memory is a plain 16-bit word (bf16_t) for both.
+// ---------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+
+template <int F> __device__ __forceinline__ bf16_t f2h(float f)
+{
+    if constexpr (F == 0) return f2bf(f);
+    else return __builtin_bit_cast(bf16_t, (_Float16)__builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f));
+}
+template <int F> __device__ __forceinline__ float h2f(bf16_t h)
+{
+    if constexpr (F == 0) return bf2f(h);
+    else return (float)__builtin_bit_cast(_Float16, h);
+}
+template <int F> __device__ __forceinline__ unsigned pack2(float lo, float hi)
+{
+    if constexpr (F == 0) return pack_bf16(lo, hi);
+    else {
+        f16x2_t r = {(_Float16)__builtin_amdgcn_fmed3f(lo, -65504.0f, 65504.0f), (_Float16)__builtin_amdgcn_fmed3f(hi, -65504.0f, 65504.0f)};
+        return __builtin_bit_cast(unsigned, r);
+    }
+}
+// the two halves of a packed pair as floats
+template <int F> __device__ __forceinline__ float lo2f(unsigned u)
+{
+    if constexpr (F == 0) return __uint_as_float(u << 16);
+    else return (float)__builtin_bit_cast(f16x2_t, u)[0];
+}
+template <int F> __device__ __forceinline__ float hi2f(unsigned u)
+{
+    if constexpr (F == 0) return __uint_as_float(u & 0xffff0000u);
+    else return (float)__builtin_bit_cast(f16x2_t, u)[1];
+}
+// D += A * B on the matrix cores, 16x16x32 and 32x32x16, 16-bit operands (eight per lane), float32 accumulators
+template <int F> __device__ __forceinline__ f32x4_t mfma16(bf16x8 a, bf16x8 b, f32x4_t c)
+{
+    if constexpr (F == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <int F> __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c)
+{
+    if constexpr (F == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// the same 16x16x32 product with the accumulator tied as destination (see the slab kernel)
+#define AZ_MFMA16_INPLACE(F, acc, a, b)                                                                              \
+    do {                                                                                                            \
+        if constexpr ((F) == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b)); \
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));                    \
+    } while (0)
+
+// ---------------------------------------------------------------------------
 // int8 planes (B,17,H,W) -> NHWC with halo, CIN0 channels (17 real + zeros)
 // ---------------------------------------------------------------------------
-template <typename T>
+template <typename T, int F = 0>
 __global__ void k_planes_to_nhwc(const int8_t *planes, T *X0, int H, int W, const int32_t *__restrict__ rows,
                                  const int32_t *__restrict__ cnt)
 {
@@ -46,7 +106,7 @@ __global__ void k_planes_to_nhwc(const int8_t *planes, T *X0, int H, int W, cons
 #pragma unroll
         for (int c = 0; c < CIN0; c++) {
             const float f = c < 17 ? (float)src[c * HW + pix] : 0.0f;
-            if constexpr (sizeof(T) == 2) v[c] = f2bf(f); else v[c] = f;
+            if constexpr (sizeof(T) == 2) v[c] = f2h<F>(f); else v[c] = f;
         }
         T *dst = X0 + ((size_t)b * PP + (y + 1) * (W + 2) + (x + 1)) * CIN0;
         constexpr int PER = 16 / (int)sizeof(T);
@@ -60,7 +120,7 @@ __global__ void k_planes_to_nhwc(const int8_t *planes, T *X0, int H, int W, cons
 // Workgroup tile 128 pixels x 128 output channels, 4 waves as 2x2, each wave a
 // 64x64 tile = 2x2 MFMA 32x32 accumulators; K step = one tap x KC channels.
 // ---------------------------------------------------------------------------
-template <int KC, bool RESID>
+template <int KC, bool RESID, int F = 0>
 __global__ __launch_bounds__(256) void k_conv3x3_bf16(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
                                                       const float *__restrict__ bias, const bf16_t *R,
                                                       bf16_t *Y, int M, int HW, int Wd, int PP, int CIN, int COUT)
@@ -128,7 +188,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const bf16_t *__restrict__
                 for (int i = 0; i < 2; i++)
 #pragma unroll
                     for (int j = 0; j < 2; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma32<F>(af[i], bf[j], acc[i][j]);
             }
         }
     }
@@ -145,8 +205,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_bf16(const bf16_t *__restrict__
                 if (m0 + row < M) {
                     size_t o = (size_t)rowoff[row] * COUT + n;
                     float v = acc[i][j][r] + bn;
-                    if (RESID) v += bf2f(R[o]);
-                    Y[o] = f2bf(fmaxf(v, 0.0f));
+                    if (RESID) v += h2f<F>(R[o]);
+                    Y[o] = f2h<F>(fmaxf(v, 0.0f));
                 }
             }
         }
@@ -179,7 +239,7 @@ __device__ __forceinline__ void glds16(const bf16_t *g, unsigned char *l)
                                      (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
 
-template <bool RESID>
+template <bool RESID, int F = 0>
 __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
                                                            const float *__restrict__ bias, const bf16_t *R,
                                                            bf16_t *Y, int M, int HW, int Wd, int PP)
@@ -251,7 +311,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16(const bf16_t *__restr
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 8; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16<F>(wf[i], xf[j], acc[i][j]);
         }
     }
     __syncthreads();
@@ -264,8 +324,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16(const bf16_t *__restr
         for (int j = 0; j < 8; j++) {
             const f32x4 a = acc[i][j];
             uint2 pk;
-            pk.x = (unsigned)f2bf(a[0] + b4.x) | ((unsigned)f2bf(a[1] + b4.y) << 16);
-            pk.y = (unsigned)f2bf(a[2] + b4.z) | ((unsigned)f2bf(a[3] + b4.w) << 16);
+            pk.x = pack2<F>(a[0] + b4.x, a[1] + b4.y);
+            pk.y = pack2<F>(a[2] + b4.z, a[3] + b4.w);
             *reinterpret_cast<uint2 *>(reg + (j * 16 + (lane & 15)) * 144 + (i * 16 + (lane >> 4) * 4) * 2) = pk;
         }
     }
@@ -287,9 +347,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16(const bf16_t *__restr
             unsigned out[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                float lo = bf2f((bf16_t)(vv[k] & 0xffff)), hi = bf2f((bf16_t)(vv[k] >> 16));
-                if (RESID) { lo += bf2f((bf16_t)(rr[k] & 0xffff)); hi += bf2f((bf16_t)(rr[k] >> 16)); }
-                out[k] = (unsigned)f2bf(fmaxf(lo, 0.f)) | ((unsigned)f2bf(fmaxf(hi, 0.f)) << 16);
+                float lo = lo2f<F>(vv[k]), hi = hi2f<F>(vv[k]);
+                if (RESID) { lo += lo2f<F>(rr[k]); hi += hi2f<F>(rr[k]); }
+                out[k] = pack2<F>(fmaxf(lo, 0.f), fmaxf(hi, 0.f));
             }
             *reinterpret_cast<uint4 *>(Y + o) = make_uint4(out[0], out[1], out[2], out[3]);
         }
@@ -301,7 +361,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16(const bf16_t *__restr
 // R and Y may be the same buffer (the tower in groups of boards writes a block's output over its residual input): every
 // output element depends on the residual at that element only, and neither pointer is declared restrict in any bf16
 // convolution kernel, so the compiler keeps each element's residual load ahead of its store.
-template <bool RESID, int NI>
+template <bool RESID, int NI, int F = 0>
 __device__ __forceinline__ void conv_epilogue(unsigned char *smem, const int *rowoff, f32x4 (&acc)[NI][8], const float *__restrict__ bias,
                                               const bf16_t *R, bf16_t *Y, int M, int m0, int wave, int lane,
                                               int wr, int cbase)
@@ -318,8 +378,8 @@ __device__ __forceinline__ void conv_epilogue(unsigned char *smem, const int *ro
         for (int j = 0; j < 8; j++) {
             const f32x4 a = acc[i][j];
             uint2 pk;
-            pk.x = pack_bf16(a[0] + b4.x, a[1] + b4.y);
-            pk.y = pack_bf16(a[2] + b4.z, a[3] + b4.w);
+            pk.x = pack2<F>(a[0] + b4.x, a[1] + b4.y);
+            pk.y = pack2<F>(a[2] + b4.z, a[3] + b4.w);
             *reinterpret_cast<uint2 *>(reg + (j * 16 + (lane & 15)) * 144 + (i * 16 + (lane >> 4) * 4) * 2) = pk;
         }
     }
@@ -347,9 +407,9 @@ __device__ __forceinline__ void conv_epilogue(unsigned char *smem, const int *ro
             unsigned out[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                float lo = __uint_as_float(vv[k] << 16), hi = __uint_as_float(vv[k] & 0xffff0000u);
-                if (RESID) { lo += __uint_as_float(rr[k] << 16); hi += __uint_as_float(rr[k] & 0xffff0000u); }
-                out[k] = pack_bf16(fmaxf(lo, 0.f), fmaxf(hi, 0.f));
+                float lo = lo2f<F>(vv[k]), hi = hi2f<F>(vv[k]);
+                if (RESID) { lo += lo2f<F>(rr[k]); hi += hi2f<F>(rr[k]); }
+                out[k] = pack2<F>(fmaxf(lo, 0.f), fmaxf(hi, 0.f));
             }
             *reinterpret_cast<uint4 *>(Y + o) = make_uint4(out[0], out[1], out[2], out[3]);
         }
@@ -394,7 +454,7 @@ __device__ __forceinline__ int xcd_tile(int wg, int nwg)
 // CW = output channels per wave (64, 32 or 16): a workgroup covers 4 * CW channels of its 256 points and blockIdx.y
 // picks which, so a batch with few tiles can still occupy the chip (each workgroup then re-reads the activation slab
 // but only its share of the weights).
-template <bool RESID, int NSP, int CIN = 256, int CW = 64>
+template <bool RESID, int NSP, int CIN = 256, int CW = 64, int F = 0>
 __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
                                                                 const float *__restrict__ bias, const bf16_t *R,
                                                                 bf16_t *Y, int M, int HW, int Wd, int PP, int npos,
@@ -496,7 +556,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
             for (int j = 0; j < 8; j++)
                 // accumulate in place: tying the destination to the C operand keeps the register allocator from
                 // renaming the 128 accumulator registers from tap to tap (which costs spills inside the loop)
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[i]), "v"(xf[j]));
+                AZ_MFMA16_INPLACE(F, acc[i][j], wf[i], xf[j]);
     };
     // One MFMA interval: 32 MFMAs with this wave's share of the LDS-DMA slipped in after the first rows.
     // dw = how many half-steps ahead the weights are fetched (3 for group 0, 2 for group 1, which issues
@@ -571,7 +631,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     // (a register-swap epilogue without the LDS round trip measured 1-3 % slower in the self-play bench)
     __syncthreads();
-    conv_epilogue<RESID, NI>(smem, rowoff, acc, bias, R, Y, M, m0, wave, lane, wr, cout0 + wc * CW);
+    conv_epilogue<RESID, NI, F>(smem, rowoff, acc, bias, R, Y, M, m0, wave, lane, wr, cout0 + wc * CW);
 }
 
 // ---------------------------------------------------------------------------
@@ -590,7 +650,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_c256_bf16_slab(const bf16_t *__
 #define V6_SLAB0 24576
 // NPW = slab pieces (16 positions x 64 B) each wave fetches per channel chunk: 6 (24 pieces) or 7 (27 distinct pieces; the
 // 28th load repeats the 27th, so that every wave issues the same number of loads and the vmcnt bookkeeping stays uniform)
-template <bool RESID, int NPW = 6>
+template <bool RESID, int NPW = 6, int F = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_conv3x3_c256_bf16_duo(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt, const float *__restrict__ bias,
                              const bf16_t *R, bf16_t *Y, int M, int HW, int Wd, int PP, int npos,
@@ -700,12 +760,12 @@ void k_conv3x3_c256_bf16_duo(const bf16_t *__restrict__ X, const bf16_t *__restr
             for (int j = 0; j < 8; j++)
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[i]), "v"(xf[j]));
+                    AZ_MFMA16_INPLACE(F, acc[i][j], wf[i], xf[j]);
         }
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __syncthreads();
-    conv_epilogue<RESID, 4>(smem, rowoff, acc, bias, R, Y, M, m0, wave, lane, wr, cout0 + wc * 64);
+    conv_epilogue<RESID, 4, F>(smem, rowoff, acc, bias, R, Y, M, m0, wave, lane, wr, cout0 + wc * 64);
 }
 
 // largest number of padded positions (incl. the one-row-plus-one halo on both sides) that a tile of

@@ -69,7 +69,7 @@ struct az_engine {
     hipEvent_t ev[AZ_EVQ][4];
     int ev_head = 0, ev_pending = 0;
     bool conv_profile = false;      // per-launch conv timing on every round (host waits for each round)
-    bool serial_towers = false;     // az_config.match_serial_towers (A/B timing: both towers of a match on one stream)
+    bool serial_towers = true;      // !az_config.match_parallel_towers: both towers of a match on the engine's one stream
     int prof_every = 0;             // > 0: per-launch conv timing on every prof_every-th round only, rounds stay queued
     bool ev_prof[AZ_EVQ] = {};      // the queued round of this event quad carries the tower's per-launch events
     uint64_t round_index = 0;
@@ -291,7 +291,7 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     D.max_turn = cfg->max_turn;
     D.d_alpha = cfg->d_alpha; D.d_epsilon = cfg->d_epsilon;
     D.c_punt = cfg->c_punt > 0.0 ? cfg->c_punt : 5.0;
-    h->serial_towers = cfg->match_serial_towers != 0;
+    h->serial_towers = cfg->match_parallel_towers == 0;
     long long ec = cfg->tree_edge_cap > 0 ? cfg->tree_edge_cap : 3LL * (cfg->max_playout + 1) * O;
     long long bc = cfg->tree_block_cap > 0 ? cfg->tree_block_cap : 8LL * (cfg->max_playout + 1);
     if (ec < O) ec = O;

@@ -54,10 +54,10 @@ class Engine:
                  max_depth=0, rng_replay=False, seed=0, record_trajectories=False, num_blocks=0, channels=256,
                  tower_dtype="bf16", device=0, search_f64=False, tree_full_policy=0, leaves_per_round=1,
                  virtual_loss=1.0, enforce_superko=False, c_punt=5.0, tower_graphs=None, conv_duo=None,
-                 tower_group_boards=None, match_serial_towers=None):
+                 tower_group_boards=None, match_parallel_towers=None):
         """The last four arguments are measurement switches (A/B timing, tests).  Left at None they follow the
         environment variables the tools/ scripts set: AZ_NO_GRAPHS, AZ_CONV_DUO=0, AZ_TOWER_GROUP_BOARDS=N,
-        AZ_MATCH_SERIAL_TOWERS; the library itself reads no environment."""
+        AZ_MATCH_PARALLEL_TOWERS; the library itself reads no environment."""
         self._L = _lib.lib()
         env = os.environ
         if tower_graphs is None:
@@ -66,8 +66,8 @@ class Engine:
             conv_duo = not env.get("AZ_CONV_DUO", "1").startswith("0")
         if tower_group_boards is None:
             tower_group_boards = int(env.get("AZ_TOWER_GROUP_BOARDS", "0"))
-        if match_serial_towers is None:
-            match_serial_towers = "AZ_MATCH_SERIAL_TOWERS" in env
+        if match_parallel_towers is None:
+            match_parallel_towers = "AZ_MATCH_PARALLEL_TOWERS" in env
         cfg = AzConfig(
             struct_size=C.sizeof(AzConfig), game=GAME_IDS[game] if isinstance(game, str) else int(game),
             board_height=board_height, board_width=board_width, k=k, n_slots=n_slots, max_playout=max_playout,
@@ -78,7 +78,7 @@ class Engine:
             device=device, leaves_per_round=int(leaves_per_round), virtual_loss=float(virtual_loss),
             tree_full_policy=int(tree_full_policy), search_f64=int(bool(search_f64)), enforce_superko=int(bool(enforce_superko)),
             c_punt=float(c_punt), tower_no_graphs=int(not tower_graphs), tower_no_duo=int(not conv_duo),
-            tower_group_boards=int(tower_group_boards), match_serial_towers=int(bool(match_serial_towers)))
+            tower_group_boards=int(tower_group_boards), match_parallel_towers=int(bool(match_parallel_towers)))
         self.cfg = cfg
         # dtype of W / P / priors / values: float64 reproduces a search fed by a float64 evaluator (dummy_eval.py:26-28)
         self.real = np.float64 if search_f64 else np.float32

@@ -95,7 +95,11 @@ typedef struct az_config {
     int32_t tower_no_duo;      /* 1: the one-workgroup slab convolution also where the two-workgroups-per-CU kernel applies */
     int32_t tower_group_boards;/* boards per group when a large batch goes through the tower in groups: 0 = automatic,
                                   -1 = never (whole batch layer by layer), N = groups of N boards */
-    int32_t match_serial_towers; /* 1: the two towers of a two-network match run one after the other on one stream */
+    int32_t match_parallel_towers; /* 0: the two towers of a two-network match run one after the other on the engine's stream.
+                                  1: the second network's tower runs beside the first on a stream of another priority (a hardware
+                                  queue of its own; +60 % match throughput when neither share fills the chip).  Off by default:
+                                  with many streams created earlier in the process, rounds of two concurrently running towers
+                                  have been seen to stop making progress on this runtime */
 } az_config;
 
 /* Fixed-layout copy of one game state (attributes of env/*.py GameState). */

@@ -69,7 +69,7 @@ def test_two_network_routing_is_exact(H, C, dtype, G, P, max_turn):
 def test_match_with_towers_in_board_groups_is_bit_identical(monkeypatch):
     """Two networks, queued rounds (batch sizes in device memory), each tower taking its share through the layers in groups
     of 420 boards - the same convolution kernel as the whole batch gets, so whole games must come out bit for bit the same
-    as with whole-batch launches.  The second tower runs beside the first on its own stream in both."""
+    as with whole-batch launches.  (Both towers run on the engine's stream, one after the other: the default.)"""
     from alphazero_amd.engine import Engine
     H, G, P, max_turn, NB = 9, 1680, 3, 5, 1
     O = H * H + 1
