@@ -783,6 +783,7 @@ static inline int conv_slab_span(int HW, int Wd, int PP)
 }
 
 // stem: 32 (zero padded) input channels -> 256, one 32-channel chunk, same kernel
+template <int F = 0>
 static inline bool launch_v5_stem(const bf16_t *X, const bf16_t *Wt, const float *bias, bf16_t *Y, int M, int HW, int Wd, int PP,
                                   hipStream_t st = 0, const int32_t *cnt = nullptr);
 
@@ -798,17 +799,18 @@ static inline int conv_channel_split(int M, int compute_units = 256)
     return 1;
 }
 
-template <bool RESID, int NSP>
+template <bool RESID, int NSP, int F = 0>
 static inline void launch_v5_cw(int cs, dim3 g, dim3 blk, hipStream_t st, const bf16_t *X, const bf16_t *Wt, const float *bias,
                                 const bf16_t *R, bf16_t *Y, int M, int HW, int Wd, int PP, int npos, const int32_t *cnt)
 {
     g.y = cs;
-    if (cs == 4) hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<RESID, NSP, 256, 16>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
-    else if (cs == 2) hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<RESID, NSP, 256, 32>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
-    else hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<RESID, NSP, 256, 64>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+    if (cs == 4) hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<RESID, NSP, 256, 16, F>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+    else if (cs == 2) hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<RESID, NSP, 256, 32, F>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+    else hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<RESID, NSP, 256, 64, F>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
 }
 
 // the two-workgroups-per-CU form: boards whose slab fits 384 or 432 positions, batches that fill the chip
+template <int F = 0>
 static inline bool launch_v6(const bf16_t *X, const bf16_t *Wt, const float *bias, const bf16_t *R, bf16_t *Y, int M, int HW, int Wd,
                              int PP, hipStream_t st = 0, const int32_t *cnt = nullptr)
 {
@@ -817,16 +819,17 @@ static inline bool launch_v6(const bf16_t *X, const bf16_t *Wt, const float *bia
     const int npos = (M / HW) * PP;
     dim3 g(2 * ((M + 255) / 256)), blk(256);
     if (span <= 24 * 16) {
-        if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16_duo<true, 6>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
-        else hipLaunchKernelGGL((k_conv3x3_c256_bf16_duo<false, 6>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+        if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16_duo<true, 6, F>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+        else hipLaunchKernelGGL((k_conv3x3_c256_bf16_duo<false, 6, F>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
     } else {
-        if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16_duo<true, 7>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
-        else hipLaunchKernelGGL((k_conv3x3_c256_bf16_duo<false, 7>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+        if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16_duo<true, 7, F>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+        else hipLaunchKernelGGL((k_conv3x3_c256_bf16_duo<false, 7, F>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
     }
     return true;
 }
 
 // cs: channel split (1, 2 or 4), 0 = choose from the batch size
+template <int F = 0>
 static inline bool launch_v5(const bf16_t *X, const bf16_t *Wt, const float *bias, const bf16_t *R, bf16_t *Y, int M, int HW, int Wd,
                              int PP, hipStream_t st = 0, const int32_t *cnt = nullptr, int cs = 0)
 {
@@ -835,18 +838,19 @@ static inline bool launch_v5(const bf16_t *X, const bf16_t *Wt, const float *bia
     dim3 g((M + 255) / 256), blk(512);
     if (cs == 0) cs = conv_channel_split(M);
     if (span <= 3 * 128) {
-        if (R) launch_v5_cw<true, 3>(cs, g, blk, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
-        else launch_v5_cw<false, 3>(cs, g, blk, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+        if (R) launch_v5_cw<true, 3, F>(cs, g, blk, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+        else launch_v5_cw<false, 3, F>(cs, g, blk, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
         return true;
     }
     if (span <= 4 * 128) {
-        if (R) launch_v5_cw<true, 4>(cs, g, blk, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
-        else launch_v5_cw<false, 4>(cs, g, blk, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+        if (R) launch_v5_cw<true, 4, F>(cs, g, blk, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
+        else launch_v5_cw<false, 4, F>(cs, g, blk, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt);
         return true;
     }
     return false;
 }
 
+template <int F>
 static inline bool launch_v5_stem(const bf16_t *X, const bf16_t *Wt, const float *bias, bf16_t *Y, int M, int HW, int Wd, int PP,
                                   hipStream_t st, const int32_t *cnt)
 {
@@ -854,8 +858,8 @@ static inline bool launch_v5_stem(const bf16_t *X, const bf16_t *Wt, const float
     const int npos = (M / HW) * PP;
     dim3 g((M + 255) / 256), blk(512);
     const bf16_t *R = nullptr;
-    if (span <= 3 * 128) { hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 3, 32>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt); return true; }
-    if (span <= 4 * 128) { hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 4, 32>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt); return true; }
+    if (span <= 3 * 128) { hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 3, 32, 64, F>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt); return true; }
+    if (span <= 4 * 128) { hipLaunchKernelGGL((k_conv3x3_c256_bf16_slab<false, 4, 32, 64, F>), g, blk, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, npos, cnt); return true; }
     return false;
 }
 
@@ -871,7 +875,7 @@ static inline bool launch_v5_stem(const bf16_t *X, const bf16_t *Wt, const float
 // NW waves per workgroup = ways the reduction axis is split; NI 16-channel blocks per workgroup; UN steps of loads
 // in flight per wave.  <8, 2, 9>: one or two boards (72 steps / 8 waves = one batch of loads, lowest latency);
 // <4, 4, 3>: up to about 16 boards (fewer, larger workgroups: less operand re-reading).
-template <bool RESID, int NW, int NI, int UN>
+template <bool RESID, int NW, int NI, int UN, int F = 0>
 __global__ __launch_bounds__(64 * NW) void k_conv3x3_bf16_small(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wt,
                                                                       const float *__restrict__ bias, const bf16_t *R,
                                                                       bf16_t *Y, int M, int HW, int Wd, int PP, int CIN,
@@ -919,7 +923,7 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_bf16_small(const bf16_t *__
                 for (int i = 0; i < NI; i++)
 #pragma unroll
                     for (int j = 0; j < 2; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][i], xf[u][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16<F>(wf[u][i], xf[u][j], acc[i][j]);
             }
         }
     }
@@ -943,24 +947,24 @@ __global__ __launch_bounds__(64 * NW) void k_conv3x3_bf16_small(const bf16_t *__
             float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
             if (RESID) {
                 const uint2 rr = *reinterpret_cast<const uint2 *>(R + o);
-                r0 = __uint_as_float(rr.x << 16); r1 = __uint_as_float(rr.x & 0xffff0000u);
-                r2 = __uint_as_float(rr.y << 16); r3 = __uint_as_float(rr.y & 0xffff0000u);
+                r0 = lo2f<F>(rr.x); r1 = hi2f<F>(rr.x);
+                r2 = lo2f<F>(rr.y); r3 = hi2f<F>(rr.y);
             }
             uint2 pk;
-            pk.x = pack_bf16(fmaxf(v[0] + b4.x + r0, 0.f), fmaxf(v[1] + b4.y + r1, 0.f));
-            pk.y = pack_bf16(fmaxf(v[2] + b4.z + r2, 0.f), fmaxf(v[3] + b4.w + r3, 0.f));
+            pk.x = pack2<F>(fmaxf(v[0] + b4.x + r0, 0.f), fmaxf(v[1] + b4.y + r1, 0.f));
+            pk.y = pack2<F>(fmaxf(v[2] + b4.z + r2, 0.f), fmaxf(v[3] + b4.w + r3, 0.f));
             *reinterpret_cast<uint2 *>(Y + o) = pk;
         }
     }
 }
 
-template <int NW, int NI, int UN>
+template <int NW, int NI, int UN, int F = 0>
 static inline void launch_small(const bf16_t *X, const bf16_t *Wt, const float *bias, const bf16_t *R, bf16_t *Y, int M, int HW, int Wd,
                                 int PP, int cin, int cout, hipStream_t st)
 {
     dim3 gs((M + 31) / 32, cout / (16 * NI)), bs(64 * NW);
-    if (R) hipLaunchKernelGGL((k_conv3x3_bf16_small<true, NW, NI, UN>), gs, bs, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, cin, cout);
-    else hipLaunchKernelGGL((k_conv3x3_bf16_small<false, NW, NI, UN>), gs, bs, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, cin, cout);
+    if (R) hipLaunchKernelGGL((k_conv3x3_bf16_small<true, NW, NI, UN, F>), gs, bs, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, cin, cout);
+    else hipLaunchKernelGGL((k_conv3x3_bf16_small<false, NW, NI, UN, F>), gs, bs, 0, st, X, Wt, bias, R, Y, M, HW, Wd, PP, cin, cout);
 }
 
 // ---------------------------------------------------------------------------

@@ -64,6 +64,17 @@ struct Tower {
     double conv_flops;
 };
 
+// dtype: 0 float32, 1 bfloat16, 2 IEEE half precision; the two 16-bit forms share every code path (format template F)
+static inline bool is16(int dtype) { return dtype != 0; }
+
+static inline bf16_t h_f2h16(float f)   // float -> IEEE half, round to nearest even (the compiler's conversion)
+{
+    const _Float16 h = (_Float16)f;
+    bf16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
 static inline bf16_t h_f2bf(float f)
 {
     unsigned int u;
@@ -79,7 +90,7 @@ static inline bf16_t h_f2bf(float f)
 // HBM-bound: the last activation tensor is read once with 16-byte loads; LPP lanes share a board point
 // (8 bf16 / 4 fp32 channels per lane per load), partial sums are folded with xor-shuffles.
 // ---------------------------------------------------------------------------
-template <typename T, bool ONEPASS>
+template <typename T, bool ONEPASS, int F = 0>
 __global__ __launch_bounds__(256) void k_head_conv(const T *__restrict__ X, const float *__restrict__ wh, const float *__restrict__ bh,
                                                    float *__restrict__ hp, float *__restrict__ hv, int HW, int Wd, int PP, int C, int LPP,
                                                    const int32_t *__restrict__ cnt)
@@ -110,7 +121,7 @@ __global__ __launch_bounds__(256) void k_head_conv(const T *__restrict__ X, cons
                 const uint4 u = *reinterpret_cast<const uint4 *>(row + c0);
                 const unsigned uu[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-                for (int k = 0; k < 4; k++) { v[2 * k] = __uint_as_float(uu[k] << 16); v[2 * k + 1] = __uint_as_float(uu[k] & 0xffff0000u); }
+                for (int k = 0; k < 4; k++) { v[2 * k] = lo2f<F>(uu[k]); v[2 * k + 1] = hi2f<F>(uu[k]); }
             } else {
                 const float4 f = *reinterpret_cast<const float4 *>(row + c0);
                 v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
@@ -296,7 +307,8 @@ Tower *tower_create(int H, int W, int O, int num_blocks, int channels, int dtype
     }
     const size_t C = channels, HW = t->HW;
     t->blob_floats = C * 9 * 17 + C + (size_t)num_blocks * 2 * (C * 9 * C + C) + 3 * C + 3 + 2 * HW * O + O + HW * 256 + 256 + 256 + 1;
-    const size_t es = dtype == 1 ? 2 : 4;
+    if (dtype < 0 || dtype > 2) { err = "tower_dtype must be 0 (float32), 1 (bfloat16) or 2 (half precision)"; return nullptr; }
+    const size_t es = is16(dtype) ? 2 : 4;
     bool ok = true;
     ok = ok && (t->w_stem = talloc<char>(t, C * 9 * CIN0 * es));
     ok = ok && (t->w_conv = talloc<char>(t, (size_t)num_blocks * 2 * C * 9 * C * es));
@@ -326,9 +338,10 @@ void tower_destroy(Tower *t)
 
 static int upload_conv(void *dst, const float *src, size_t n, int dtype, hipStream_t st)
 {
-    if (dtype == 1) {
+    if (is16(dtype)) {
         std::vector<bf16_t> tmp(n);
-        for (size_t i = 0; i < n; i++) tmp[i] = h_f2bf(src[i]);
+        if (dtype == 1) for (size_t i = 0; i < n; i++) tmp[i] = h_f2bf(src[i]);
+        else for (size_t i = 0; i < n; i++) tmp[i] = h_f2h16(src[i]);
         if (hipMemcpyAsync(dst, tmp.data(), n * 2, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
         return hipStreamSynchronize(st) == hipSuccess ? 0 : -1;
     }
@@ -358,7 +371,7 @@ int tower_load(Tower *t, const float *blob, size_t n, hipStream_t st, std::strin
         p += C;
     }
     for (int l = 0; l < 2 * t->NB; l++) {
-        rc |= upload_conv((char *)t->w_conv + (size_t)l * C * 9 * C * (t->dtype == 1 ? 2 : 4), p, C * 9 * C, t->dtype, st);
+        rc |= upload_conv((char *)t->w_conv + (size_t)l * C * 9 * C * (is16(t->dtype) ? 2 : 4), p, C * 9 * C, t->dtype, st);
         p += C * 9 * C;
         rc |= upload_conv(t->b_conv + (size_t)l * C, p, C, 0, st);
         p += C;
@@ -379,46 +392,40 @@ int tower_load(Tower *t, const float *blob, size_t n, hipStream_t st, std::strin
 // Weights from a blob that already lies in device memory.  k_weights_cvt: n floats -> the compute type (bf16 with the same
 // round-to-nearest-even, NaN kept quiet, as h_f2bf on the host; float32 copied).  k_stem_pad: the stem's [C][9][17] rows
 // padded with zeros to [C][9][CIN0].
-template <typename T>
-__global__ void k_weights_cvt(const float *__restrict__ src, T *__restrict__ dst, size_t n)
+// one weight: float -> the compute type, exactly as the host conversion of tower_load does it (weights are not clamped)
+template <typename T, int F>
+__device__ __forceinline__ T weight_cvt(float f)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        if constexpr (sizeof(T) == 2) {
-            unsigned u = __float_as_uint(src[i]);
-            if ((u & 0x7fffffffu) > 0x7f800000u) dst[i] = (T)((u >> 16) | 0x40);
-            else { u += 0x7fffu + ((u >> 16) & 1u); dst[i] = (T)(u >> 16); }
-        } else {
-            dst[i] = src[i];
-        }
-    }
+    if constexpr (sizeof(T) == 4) return f;
+    else if constexpr (F == 0) return f2bf(f);
+    else return __builtin_bit_cast(bf16_t, (_Float16)f);
 }
 
-template <typename T>
+template <typename T, int F>
+__global__ void k_weights_cvt(const float *__restrict__ src, T *__restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = weight_cvt<T, F>(src[i]);
+}
+
+template <typename T, int F>
 __global__ void k_stem_pad(const float *__restrict__ src, T *__restrict__ dst, int rows)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * CIN0) return;
     const int r = i / CIN0, ci = i - r * CIN0;
-    const float f = ci < 17 ? src[(size_t)r * 17 + ci] : 0.0f;
-    if constexpr (sizeof(T) == 2) {
-        unsigned u = __float_as_uint(f);
-        if ((u & 0x7fffffffu) > 0x7f800000u) dst[i] = (T)((u >> 16) | 0x40);
-        else { u += 0x7fffu + ((u >> 16) & 1u); dst[i] = (T)(u >> 16); }
-    } else {
-        dst[i] = f;
-    }
+    dst[i] = weight_cvt<T, F>(ci < 17 ? src[(size_t)r * 17 + ci] : 0.0f);
 }
 
-template <typename T>
+template <typename T, int F>
 static void load_dev_t(Tower *t, const float *p, hipStream_t st)
 {
     const size_t C = t->C, HW = t->HW, O = t->O;
     auto cvt = [&](void *dst, const float *src, size_t n) {
         const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
-        hipLaunchKernelGGL((k_weights_cvt<T>), dim3(blocks), dim3(256), 0, st, src, (T *)dst, n);
+        hipLaunchKernelGGL((k_weights_cvt<T, F>), dim3(blocks), dim3(256), 0, st, src, (T *)dst, n);
     };
     auto cpy = [&](float *dst, const float *src, size_t n) { hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st); };
-    hipLaunchKernelGGL((k_stem_pad<T>), dim3(((unsigned)(C * 9 * CIN0) + 255) / 256), dim3(256), 0, st, p, (T *)t->w_stem, (int)(C * 9));
+    hipLaunchKernelGGL((k_stem_pad<T, F>), dim3(((unsigned)(C * 9 * CIN0) + 255) / 256), dim3(256), 0, st, p, (T *)t->w_stem, (int)(C * 9));
     p += C * 9 * 17;
     cpy(t->b_stem, p, C); p += C;
     for (int l = 0; l < 2 * t->NB; l++) {
@@ -449,58 +456,55 @@ int tower_load_dev(Tower *t, const float *dev_blob, size_t n, hipStream_t st, st
         err = "blob_dev is not a device pointer";
         return -1;
     }
-    if (t->dtype == 1) load_dev_t<bf16_t>(t, dev_blob, st); else load_dev_t<float>(t, dev_blob, st);
+    if (t->dtype == 1) load_dev_t<bf16_t, 0>(t, dev_blob, st);
+    else if (t->dtype == 2) load_dev_t<bf16_t, 1>(t, dev_blob, st);
+    else load_dev_t<float, 0>(t, dev_blob, st);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { err = "device-side weight load failed"; return -1; }
     t->ready = true;
     return 0;
 }
 
-template <typename T>
-static void launch_conv(const Tower *t, const T *X, const T *Wt, const float *bias, const T *R, T *Y, int B, int cin, hipStream_t st,
-                        const int32_t *cnt = nullptr);
-
-template <>
-void launch_conv<bf16_t>(const Tower *t, const bf16_t *X, const bf16_t *Wt, const float *bias, const bf16_t *R, bf16_t *Y, int B,
-                         int cin, hipStream_t st, const int32_t *cnt)
+template <int F>
+static void launch_conv16(const Tower *t, const bf16_t *X, const bf16_t *Wt, const float *bias, const bf16_t *R, bf16_t *Y, int B,
+                          int cin, hipStream_t st, const int32_t *cnt)
 {
     // batches that fill the chip with whole 256-point tiles, boards whose slab fits 3 x 128 positions (19x19): the form
     // with two 4-wave workgroups per compute unit (each 256 points x 128 channels)
     const bool duo = t->use_duo && cin == 256 && t->C == 256 && conv_channel_split(B * t->HW) == 1;
     if (cnt) {  // device-side batch size: only the slab kernels take it (tower_takes_device_count() said they apply)
         const int Mc = B * t->HW;
-        if (cin == CIN0) launch_v5_stem(X, Wt, bias, Y, Mc, t->HW, t->W, t->PP, st, cnt);
-        else if (!(duo && launch_v6(X, Wt, bias, R, Y, Mc, t->HW, t->W, t->PP, st, cnt))) launch_v5(X, Wt, bias, R, Y, Mc, t->HW, t->W, t->PP, st, cnt);
+        if (cin == CIN0) launch_v5_stem<F>(X, Wt, bias, Y, Mc, t->HW, t->W, t->PP, st, cnt);
+        else if (!(duo && launch_v6<F>(X, Wt, bias, R, Y, Mc, t->HW, t->W, t->PP, st, cnt))) launch_v5<F>(X, Wt, bias, R, Y, Mc, t->HW, t->W, t->PP, st, cnt);
         return;
     }
     const int M = B * t->HW;
     dim3 grid((M + 127) / 128, t->C / 128), block(256);
     // a few positions only: spread them over many small workgroups instead of a handful of 256-point tiles
     if (M <= SMALL_BATCH_POINTS && cin % 32 == 0 && t->C % 64 == 0) {
-        if (M <= 722) launch_small<8, 2, 9>  /* one or two 19x19 boards */(X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C, st);
-        else launch_small<4, 4, 3>(X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C, st);
+        if (M <= 722) launch_small<8, 2, 9, F>  /* one or two 19x19 boards */(X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C, st);
+        else launch_small<4, 4, 3, F>(X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C, st);
         return;
     }
     if (cin == 256 && t->C == 256) {
-        if (duo && launch_v6(X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, st)) return;
+        if (duo && launch_v6<F>(X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, st)) return;
         // slab kernel when a 256-pixel tile spans at most 512 padded positions (boards of 8x8 and larger)
-        if (launch_v5(X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, st)) return;
+        if (launch_v5<F>(X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, st)) return;
         dim3 g2((M + 255) / 256), b2(512);
-        if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16<true>), g2, b2, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP);
-        else hipLaunchKernelGGL((k_conv3x3_c256_bf16<false>), g2, b2, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP);
+        if (R) hipLaunchKernelGGL((k_conv3x3_c256_bf16<true, F>), g2, b2, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP);
+        else hipLaunchKernelGGL((k_conv3x3_c256_bf16<false, F>), g2, b2, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP);
         return;
     }
-    if (cin == CIN0 && CIN0 == 32 && t->C == 256 && !R && launch_v5_stem(X, Wt, bias, Y, M, t->HW, t->W, t->PP, st)) return;
+    if (cin == CIN0 && CIN0 == 32 && t->C == 256 && !R && launch_v5_stem<F>(X, Wt, bias, Y, M, t->HW, t->W, t->PP, st)) return;
     if (cin == CIN0)
-        hipLaunchKernelGGL((k_conv3x3_bf16<32, false>), grid, block, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C);
+        hipLaunchKernelGGL((k_conv3x3_bf16<32, false, F>), grid, block, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C);
     else if (R)
-        hipLaunchKernelGGL((k_conv3x3_bf16<64, true>), grid, block, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C);
+        hipLaunchKernelGGL((k_conv3x3_bf16<64, true, F>), grid, block, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C);
     else
-        hipLaunchKernelGGL((k_conv3x3_bf16<64, false>), grid, block, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C);
+        hipLaunchKernelGGL((k_conv3x3_bf16<64, false, F>), grid, block, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C);
 }
 
-template <>
-void launch_conv<float>(const Tower *t, const float *X, const float *Wt, const float *bias, const float *R, float *Y, int B, int cin,
-                        hipStream_t st, const int32_t *)
+static void launch_conv32(const Tower *t, const float *X, const float *Wt, const float *bias, const float *R, float *Y, int B, int cin,
+                          hipStream_t st)
 {
     const int M = B * t->HW;
     dim3 grid((M + 63) / 64, t->C / 64), block(256);
@@ -510,6 +514,14 @@ void launch_conv<float>(const Tower *t, const float *X, const float *Wt, const f
         hipLaunchKernelGGL((k_conv3x3_f32<false>), grid, block, 0, st, X, Wt, bias, R, Y, M, t->HW, t->W, t->PP, cin, t->C);
 }
 
+template <typename T, int F>
+static void launch_conv(const Tower *t, const T *X, const T *Wt, const float *bias, const T *R, T *Y, int B, int cin, hipStream_t st,
+                        const int32_t *cnt = nullptr)
+{
+    if constexpr (sizeof(T) == 2) launch_conv16<F>(t, X, Wt, bias, R, Y, B, cin, st, cnt);
+    else launch_conv32(t, X, Wt, bias, R, Y, B, cin, st);
+}
+
 // The tower in three stages, so that a large batch can take the middle one in groups of boards:
 //   tower_planes  int8 planes of `B` boards -> the 32-channel NHWC input (rows / count as the caller gave them)
 //   tower_layers  stem, residual blocks and the heads' 1x1 convolutions for the `B` boards that start at board `first` of the
@@ -517,28 +529,28 @@ void launch_conv<float>(const Tower *t, const float *X, const float *Wt, const f
 //                 second convolution of a block writes its output over its residual input (each output element depends on the
 //                 residual at that element only and nobody else reads it), so two activation buffers are live, not three.
 //   tower_head_fc policy / value fully connected layers of `B` boards into the caller's rows
-template <typename T>
+template <typename T, int F>
 static void tower_planes(Tower *t, const int8_t *planes, int B, hipStream_t st, const int32_t *rows, const int32_t *cnt)
 {
     const int ysplit = B < 64 ? 8 : 1;  // few boards: several workgroups per board in the memory-bound kernels
-    hipLaunchKernelGGL((k_planes_to_nhwc<T>), dim3(B, ysplit), dim3(256), 0, st, planes, (T *)t->X0, t->H, t->W, rows, cnt);
+    hipLaunchKernelGGL((k_planes_to_nhwc<T, F>), dim3(B, ysplit), dim3(256), 0, st, planes, (T *)t->X0, t->H, t->W, rows, cnt);
 }
 
-template <typename T>
+template <typename T, int F>
 static void tower_layers(Tower *t, int B, size_t first, hipStream_t st, const int32_t *cnt, bool alias)
 {
     const size_t C = t->C;
     T *X0 = (T *)t->X0 + first * t->PP * CIN0, *X = (T *)t->X, *Tm = (T *)t->T, *Y = alias ? X : (T *)t->Y;
     float *hp = t->hp + first * 2 * t->HW, *hv = t->hv + first * t->HW;
-    launch_conv<T>(t, X0, (const T *)t->w_stem, t->b_stem, (const T *)nullptr, X, B, CIN0, st, cnt);
+    launch_conv<T, F>(t, X0, (const T *)t->w_stem, t->b_stem, (const T *)nullptr, X, B, CIN0, st, cnt);
     for (int l = 0; l < t->NB; l++) {
         const T *w1 = (const T *)t->w_conv + (size_t)(2 * l) * C * 9 * C;
         const T *w2 = (const T *)t->w_conv + (size_t)(2 * l + 1) * C * 9 * C;
         const bool prof = t->profile && (size_t)t->evs_used + 4 <= t->evs.size();
         if (prof) { t->ev_boards[t->evs_used / 2] = B; hipEventRecord(t->evs[t->evs_used++], st); }
-        launch_conv<T>(t, X, w1, t->b_conv + (size_t)(2 * l) * C, (const T *)nullptr, Tm, B, (int)C, st, cnt);
+        launch_conv<T, F>(t, X, w1, t->b_conv + (size_t)(2 * l) * C, (const T *)nullptr, Tm, B, (int)C, st, cnt);
         if (prof) { hipEventRecord(t->evs[t->evs_used++], st); t->ev_boards[t->evs_used / 2] = B; hipEventRecord(t->evs[t->evs_used++], st); }
-        launch_conv<T>(t, Tm, w2, t->b_conv + (size_t)(2 * l + 1) * C, X, Y, B, (int)C, st, cnt);
+        launch_conv<T, F>(t, Tm, w2, t->b_conv + (size_t)(2 * l + 1) * C, X, Y, B, (int)C, st, cnt);
         if (prof) hipEventRecord(t->evs[t->evs_used++], st);
         T *tmp = X; X = Y; Y = tmp;
     }
@@ -548,10 +560,10 @@ static void tower_layers(Tower *t, int B, size_t first, hipStream_t st, const in
     // one workgroup per board reads 185 KB (19x19) at a time; below about 4 workgroups per compute unit the boards are cut
     const int ysplit = B < 64 ? 8 : (B < 4 * t->cus ? 4 : 1);
     if (chunks == lpp)
-        hipLaunchKernelGGL((k_head_conv<T, true>), dim3(B, ysplit), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, hp, hv, t->HW,
+        hipLaunchKernelGGL((k_head_conv<T, true, F>), dim3(B, ysplit), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, hp, hv, t->HW,
                            t->W, t->PP, (int)C, lpp, cnt);
     else
-        hipLaunchKernelGGL((k_head_conv<T, false>), dim3(B, ysplit), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, hp, hv, t->HW,
+        hipLaunchKernelGGL((k_head_conv<T, false, F>), dim3(B, ysplit), dim3(256), 0, st, (const T *)X, t->w_head, t->b_head, hp, hv, t->HW,
                            t->W, t->PP, (int)C, lpp, cnt);
 }
 
@@ -570,7 +582,7 @@ static void tower_head_fc(Tower *t, int B, float *priors, float *values, hipStre
 // per buffer); the last group of a batch takes what is left.
 static int tower_group_boards(const Tower *t, int B)
 {
-    if (t->group_boards < 0 || t->dtype != 1 || t->C != 256) return 0;
+    if (t->group_boards < 0 || !is16(t->dtype) || t->C != 256) return 0;
     int g = t->group_boards;
     if (g == 0) {
         g = GROUP_ROUNDS * t->cus * 256 / t->HW;
@@ -587,21 +599,21 @@ __global__ void k_group_counts(const int32_t *__restrict__ cnt, int32_t *__restr
     if (i < n) gcnt[i] = min(max(*cnt - i * g, 0), g);
 }
 
-template <typename T>
+template <typename T, int F>
 static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float *values, hipStream_t st, const int32_t *rows,
                      const int32_t *cnt)
 {
     const int g = tower_group_boards(t, B);
-    tower_planes<T>(t, planes, B, st, rows, cnt);
+    tower_planes<T, F>(t, planes, B, st, rows, cnt);
     if (g == 0) {
-        tower_layers<T>(t, B, 0, st, cnt, false);
+        tower_layers<T, F>(t, B, 0, st, cnt, false);
     } else {
         // the i-th group holds boards i*g ... of the batch (of the compacted batch when the caller lists rows)
         const int n = (B + g - 1) / g;
         if (cnt) hipLaunchKernelGGL(k_group_counts, dim3(1), dim3(MAX_GROUPS), 0, st, cnt, t->gcnt, g, n);
         for (int i = 0; i < n; i++) {
             const int b0 = i * g;
-            tower_layers<T>(t, B - b0 < g ? B - b0 : g, (size_t)b0, st, cnt ? t->gcnt + i : nullptr, true);
+            tower_layers<T, F>(t, B - b0 < g ? B - b0 : g, (size_t)b0, st, cnt ? t->gcnt + i : nullptr, true);
         }
     }
     tower_head_fc(t, B, priors, values, st, rows, cnt);
@@ -612,7 +624,7 @@ static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float
 // taken into account): the name a profiler shows, for labelling measurements.
 const char *tower_conv_kernel_name(const Tower *t, int B, bool device_count)
 {
-    if (t->dtype != 1) return "k_conv3x3_f32 (vector ALU, float32 operands, float64 accumulation)";
+    if (!is16(t->dtype)) return "k_conv3x3_f32 (vector ALU, float32 operands, float64 accumulation)";
     const int g = tower_group_boards(t, B);
     const int M = (g ? g : B) * t->HW;
     if (!device_count && M <= SMALL_BATCH_POINTS && t->C % 64 == 0) return "k_conv3x3_bf16_small (32 points x 32/64 channels per workgroup, reduction axis split over the waves)";
@@ -624,9 +636,17 @@ const char *tower_conv_kernel_name(const Tower *t, int B, bool device_count)
     return "k_conv3x3_c256_bf16 (per-tap gather of both operands, bf16 MFMA 16x16x32)";
 }
 
+static int forward_any(Tower *t, const int8_t *planes, int B, float *priors, float *values, hipStream_t st, const int32_t *rows,
+                       const int32_t *cnt)
+{
+    if (t->dtype == 1) return forward_t<bf16_t, 0>(t, planes, B, priors, values, st, rows, cnt);
+    if (t->dtype == 2) return forward_t<bf16_t, 1>(t, planes, B, priors, values, st, rows, cnt);
+    return forward_t<float, 0>(t, planes, B, priors, values, st, rows, cnt);
+}
+
 bool tower_takes_device_count(const Tower *t, int B)
 {
-    return t->dtype == 1 && t->C == 256 && CIN0 == 32 && conv_slab_span(t->HW, t->W, t->PP) <= 4 * 128 && B >= 1 && B <= t->maxB &&
+    return is16(t->dtype) && t->C == 256 && CIN0 == 32 && conv_slab_span(t->HW, t->W, t->PP) <= 4 * 128 && B >= 1 && B <= t->maxB &&
            (size_t)B * t->HW > (size_t)DEVICE_COUNT_MIN_POINTS;  // below that a half-empty batch belongs to the kernels for few boards
 }
 
@@ -645,8 +665,7 @@ int tower_forward(Tower *t, const int8_t *planes_dev, int B, float *priors_dev, 
                 break;  // fall back to plain launches below
             }
         if (t->graphs.size() < 16 && hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
-            const int crc = t->dtype == 1 ? forward_t<bf16_t>(t, planes_dev, B, priors_dev, values_dev, st, rows_dev, nullptr)
-                                          : forward_t<float>(t, planes_dev, B, priors_dev, values_dev, st, rows_dev, nullptr);
+            const int crc = forward_any(t, planes_dev, B, priors_dev, values_dev, st, rows_dev, nullptr);
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
             const hipError_t e = hipStreamEndCapture(st, &graph);
@@ -661,8 +680,7 @@ int tower_forward(Tower *t, const int8_t *planes_dev, int B, float *priors_dev, 
             t->use_graphs = false;  // capture is not available here: plain launches from now on
         }
     }
-    int rc = t->dtype == 1 ? forward_t<bf16_t>(t, planes_dev, B, priors_dev, values_dev, st, rows_dev, count_dev)
-                           : forward_t<float>(t, planes_dev, B, priors_dev, values_dev, st, rows_dev, count_dev);
+    int rc = forward_any(t, planes_dev, B, priors_dev, values_dev, st, rows_dev, count_dev);
     if (rc) err = std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError());
     return rc;
 }

@@ -74,7 +74,7 @@ class Engine:
             transform_types=transform_types, dirichlet_before=dirichlet_before, max_turn=max_turn, d_alpha=d_alpha,
             d_epsilon=d_epsilon, tree_edge_cap=tree_edge_cap, tree_block_cap=tree_block_cap, max_depth=max_depth,
             rng_replay=int(rng_replay), seed=seed, record_trajectories=int(record_trajectories), num_blocks=num_blocks,
-            channels=channels, tower_dtype={"fp32": 0, "bf16": 1}[tower_dtype] if isinstance(tower_dtype, str) else int(tower_dtype),
+            channels=channels, tower_dtype={"fp32": 0, "bf16": 1, "f16": 2}[tower_dtype] if isinstance(tower_dtype, str) else int(tower_dtype),
             device=device, leaves_per_round=int(leaves_per_round), virtual_loss=float(virtual_loss),
             tree_full_policy=int(tree_full_policy), search_f64=int(bool(search_f64)), enforce_superko=int(bool(enforce_superko)),
             c_punt=float(c_punt), tower_no_graphs=int(not tower_graphs), tower_no_duo=int(not conv_duo),

@@ -206,7 +206,9 @@ def parse_args(argv=None):
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--blocks", type=int, default=20, help="residual blocks after the stem")
     ap.add_argument("--channels", type=int, default=256)
-    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp32"],
+                    help="storage type of the tower's weights and activations: bf16 (the headline), f16 (IEEE half: same matrix-core "
+                         "rate, 8 times finer rounding), fp32 (vector-ALU parity tower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-telemetry", action="store_true", help="no rocm-smi sampling during the timed region (always off under a profiler)")
     ap.add_argument("--no-exchange", action="store_true", help="skip the weight-update / trajectory-gather exercise after the timed region")
@@ -310,10 +312,10 @@ def exchange_exercise(eng, parallel, torch, dist, rank, world, dev, blob_t, O, n
 
 
 def tower_parity(torch, np, eng, H, O, blocks, channels, planes, device):
-    """bf16 tower against the fp32 tower of the same library on the same boards and weights: the bench's architecture with
-    batch-norm statistics calibrated on data (as a trained network's are; the timed run itself uses untouched statistics,
-    with which a random 20-block tower has logits of magnitude 50 and no tolerance means anything).  96 boards, so the
-    bf16 side runs the tiled kernels of large batches."""
+    """The 16-bit towers (bf16 and half precision) against the fp32 tower of the same library on the same boards and weights:
+    the bench's architecture with batch-norm statistics calibrated on data (as a trained network's are; the timed run itself
+    uses untouched statistics, with which a random 20-block tower has logits of magnitude 50 and no tolerance means
+    anything).  96 boards, so the 16-bit side runs the tiled kernels of large batches."""
     from alphazero_amd.engine import Engine
     from alphazero_amd.network.model import calibrate_bn, fold_to_blob, random_net
     B = min(96, planes.shape[0])
@@ -322,19 +324,19 @@ def tower_parity(torch, np, eng, H, O, blocks, channels, planes, device):
     calibrate_bn(net, torch.from_numpy(x[:4].astype(np.float32)))
     blob = fold_to_blob(net)
     res = {}
-    for dt in ("bf16", "fp32"):
+    for dt in ("bf16", "f16", "fp32"):
         e = Engine(eng.game, H, H, eng.cfg.k, n_slots=B, num_blocks=blocks, channels=channels, tower_dtype=dt, device=device)
         e.tower_load(blob)
         res[dt] = e.tower_forward(x)
-        kern = e.tower_conv_kernel() if dt == "bf16" else None
         if dt == "bf16":
-            res["kernel"] = kern
+            res["kernel"] = e.tower_conv_kernel()
         e.close()
-    dp = np.abs(res["bf16"][0] - res["fp32"][0]); dv = np.abs(res["bf16"][1] - res["fp32"][1])
-    out = {"what": "bf16 tower against the fp32 tower (same library, same weights, batch-norm statistics calibrated) on %d leaf boards of this run" % B,
-           "kernel": res["kernel"], "priors_max_abs_diff": float(dp.max()), "value_max_abs_diff": float(dv.max()),
-           "value_mean_abs_diff": float(dv.mean()), "bound_bf16": 1e-2, "priors_within_bound": bool(dp.max() <= 1e-2),
-           "value_within_bound": bool(dv.max() <= 1e-2)}
+    out = {"what": "16-bit towers against the fp32 tower (same library, same weights, batch-norm statistics calibrated) on %d leaf boards of this run" % B,
+           "kernel": res["kernel"], "bound_16bit": 1e-2}
+    for dt in ("bf16", "f16"):
+        dp = np.abs(res[dt][0] - res["fp32"][0]); dv = np.abs(res[dt][1] - res["fp32"][1])
+        out[dt] = {"priors_max_abs_diff": float(dp.max()), "value_max_abs_diff": float(dv.max()), "value_mean_abs_diff": float(dv.mean()),
+                   "priors_within_bound": bool(dp.max() <= 1e-2), "value_within_bound": bool(dv.max() <= 1e-2)}
     try:
         with open(os.path.join(ROOT, "profiles", "round3_bf16_search_effect.json")) as f:
             out["search_effect"] = json.load(f)
@@ -446,7 +448,7 @@ def main(args):
         except Exception as e:  # noqa: BLE001 - the measured line must survive a failed exercise, and say so
             exchange = {"error": "%s: %s" % (type(e).__name__, e)}
     parity = None
-    if rank == 0 and args.dtype == "bf16" and not args.no_tower_parity:
+    if rank == 0 and args.dtype != "fp32" and not args.no_tower_parity:
         try:
             planes, valid = eng.leaf_batch()
             parity = tower_parity(torch, np, eng, H, O, args.blocks, args.channels, planes[np.flatnonzero(valid)], local_rank)
@@ -459,8 +461,9 @@ def main(args):
         # the tower takes a large batch through its layers in groups of boards: a launch covers one group
         boards_per_launch = c["conv_flops_per_launch"] / (2.0 * H * H * 9.0 * args.channels * args.channels)
         traffic, traffic_src = measured_traffic(boards_per_launch, H, args.channels) if args.dtype == "bf16" and boards_per_launch > 0 else (None, None)
-        # the bf16 kernels run on the matrix cores; the fp32 tower (parity mode) is a vector-ALU kernel
-        peak, bound = (MFMA_PEAK_TFLOPS_BF16, "mfma") if args.dtype == "bf16" else (VALU_PEAK_TFLOPS_FP32, "valu")
+        # the 16-bit kernels run on the matrix cores (bf16 and f16 have the same dense peak); the fp32 tower (parity mode) is a
+        # vector-ALU kernel
+        peak, bound = (MFMA_PEAK_TFLOPS_BF16, "mfma") if args.dtype != "fp32" else (VALU_PEAK_TFLOPS_FP32, "valu")
         out = {
             "metric": "self-play moves/sec + MCTS sims/sec (node), Go 19x19 800 sims, 1/2/4/8 GPUs",
             "value": moves_per_s, "unit": "moves/s", "sims_per_sec": sims_per_s,

@@ -45,6 +45,7 @@ extern "C" {
 
 #define AZ_TOWER_FP32 0
 #define AZ_TOWER_BF16 1
+#define AZ_TOWER_F16 2   /* IEEE half precision: same matrix-core rate and bytes as bf16, 11 significant bits instead of 8 */
 
 typedef struct az_engine az_engine;
 
@@ -69,7 +70,8 @@ typedef struct az_config {
     /* tower (AlphaZero/network/model.py:39-88) */
     int32_t num_blocks;        /* residual blocks; 0 = no tower (priors must be injected) */
     int32_t channels;          /* 256 in the reference (model.py:47,55-56) */
-    int32_t tower_dtype;       /* AZ_TOWER_FP32 / AZ_TOWER_BF16 */
+    int32_t tower_dtype;       /* AZ_TOWER_FP32 / AZ_TOWER_BF16 / AZ_TOWER_F16: storage type of the tower's weights and activations
+                                  (accumulation is float32 in the 16-bit forms, float64 in the float32 form) */
     int32_t device;            /* HIP device ordinal */
     int32_t leaves_per_round;  /* 0/1: one playout in flight per tree, as the reference (search/mcts.py:295-296) - the only
                                   setting held to the reference's visit counts.  K > 1: K leaves of each tree per round

@@ -54,7 +54,8 @@ def test_plain_bench_command_with_two_gpus_runs_two_ranks():
     ex = d["exchange"]
     assert "error" not in ex, ex
     assert ex["world"] == 2 and ex["weights"]["bytes"] > 0 and ex["trajectories"]["received_ok"]
-    assert ex["trajectories"]["bytes_into_rank0"] == ex["trajectories"]["packed_bytes_per_rank"] > 0
+    # rank 1's packed games arrived at rank 0 (its random games pack to about, not exactly, rank 0's size)
+    assert 0.9 < ex["trajectories"]["bytes_into_rank0"] / ex["trajectories"]["packed_bytes_per_rank"] < 1.1
     assert ex["trajectories"]["packed_bytes_per_rank"] < ex["trajectories"]["dense_bytes_per_rank"] // 3
 
 

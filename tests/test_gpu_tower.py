@@ -1,6 +1,6 @@
 """GPU numerics: HIP tower vs the fp32 CPU restatement of network/model.py (oracle/tower_ref.py).
-Tolerances are the north star's: 1e-5 abs for fp32, 1e-2 abs for bf16 (on softmax priors and the
-tanh value)."""
+Tolerances: 1e-5 abs for fp32, 1e-2 abs for the 16-bit towers (bf16 and half precision), on softmax priors and the tanh
+value.  Where a case cannot hold the literal 1e-2 (the bf16 value at 10 and 20 blocks) its test id says so."""
 import numpy as np
 import pytest
 import torch
@@ -9,10 +9,10 @@ from oracle import tower_ref
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp32": 1e-5, "bf16": 1e-2}
+TOL = {"fp32": 1e-5, "bf16": 1e-2, "f16": 1e-2}
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "f16"])
 @pytest.mark.parametrize("game,H,W,NB,C,B", [
     ("mnk", 3, 3, 2, 128, 5),
     ("reversi", 8, 8, 3, 128, 9),
@@ -71,18 +71,19 @@ def _assert_close(p, v, net, NB, x, tol):
     ("mnk", 15, 150),      # 132 tiles, 27 pieces (394 positions)
     ("go", 19, 64),        # 91 tiles: two workgroups per tile (32 channels per wave)
 ])
-def test_full_tile_conv_kernels_match_fp32_reference(game, H, B):
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_full_tile_conv_kernels_match_fp32_reference(dtype, game, H, B):
     from alphazero_amd.engine import Engine
     from alphazero_amd.network.model import fold_to_blob, random_net
     O = H * H + (0 if game == "mnk" else 1)
     NB = 1
     net = random_net(H, H, O, NB, 256, seed=H + B, perturb_bn=True)
-    eng = Engine(game, H, H, 5, n_slots=B, num_blocks=NB, channels=256, tower_dtype="bf16")
+    eng = Engine(game, H, H, 5, n_slots=B, num_blocks=NB, channels=256, tower_dtype=dtype)
     eng.tower_load(fold_to_blob(net))
     x = _boards(B, H, H, seed=B)
     p, v = eng.tower_forward(x)
     pick = np.array([0, 1, 2, B // 2, B // 2 + 1, B - 3, B - 2, B - 1])
-    _assert_close(p[pick], v[pick], net, NB, x[pick], TOL["bf16"])
+    _assert_close(p[pick], v[pick], net, NB, x[pick], TOL[dtype])
     assert np.allclose(p.sum(axis=1), 1.0, atol=1e-4)
     eng.close()
 
@@ -199,34 +200,45 @@ def _deep_net(H, O, NB, seed):
 # The depths the configurations name: 6 blocks (Reversi), 10 (Go 9x9, 15x15), 20 (Go 19x19), 256 channels.
 # Anchor: the restatement evaluated in float64 (the exact value of the reference's formula).
 #   fp32 tower: priors and value within 1e-5.
-#   bf16 tower: priors within 1e-2 at every depth (measured: 2e-3 and less).  The value of a *random* network of 6 and
-#   more blocks is more sensitive than 1e-2 to bf16 rounding itself: a CPU model of the same arithmetic (bf16 weights and
-#   activations, float32 accumulation: oracle/tower_ref.forward_bf16_model) lands 0.5e-2 .. 4e-2 from the float64 value,
-#   and so does the HIP tower.  (Random ReLU towers amplify perturbations from block to block, the residual stream is
-#   re-rounded after every block, and the value is one scalar read off the whole board; the priors, a softmax over
-#   small logits, move by a tenth of that.)  The bound on the value is therefore 1e-2 plus three times the CPU model's
-#   own distance from the anchor on the same boards - the kernels may not add to what the number format costs - and
-#   never more than 1e-1.
-def _depth_check(p, v, net, NB, x, dtype, H, O):
+#   f16 tower (half precision): priors and value within the literal 1e-2 at every depth (measured: 4e-3 and less).
+#   bf16 tower: priors within the literal 1e-2 at every depth (measured: 3e-3 and less); value within the literal 1e-2 at 6
+#   blocks.  At 10 and 20 blocks the bf16 VALUE is 1e-2 ... 4e-2 away, for any bf16 implementation: a CPU model of the same
+#   arithmetic (oracle/tower_ref.forward_bf16_model) is as far from the float64 value as the HIP tower, and no variant of
+#   the arithmetic that keeps bf16 operands on the matrix cores gets closer (tools/tower_arith_variants.py).  Those cases
+#   carry "value_widened" in their id and are held to 1e-2 + 3 x the CPU model's own distance on the same boards (never
+#   more than 1e-1): the kernels may not add to what the number format costs.
+LITERAL, WIDENED = "literal_1e-2", "value_widened_to_bf16_model"
+
+
+def _depth_check(p, v, net, NB, x, dtype, H, O, value_bound=LITERAL):
     rp, rv = tower_ref.forward(net.state_dict(), torch.from_numpy(x).float(), NB, dtype=torch.float64)
     rp, rv = rp.numpy(), rv.numpy()
     assert np.all(np.isfinite(p)) and np.all(np.isfinite(v))
     ep, ev = np.abs(p - rp).max(), np.abs(v - rv).max()
+    print("%s: value error %.2e, priors error %.2e" % (dtype, ev, ep))
     if dtype == "fp32":
         assert ep <= 1e-5 and ev <= 1e-5, (ep, ev)
         return
     assert ep <= 1e-2, ep
+    if value_bound == LITERAL:
+        assert ev <= 1e-2, ev
+        return
+    assert dtype == "bf16"
     from alphazero_amd.network.model import fold_to_blob
     mp, mv = tower_ref.forward_bf16_model(fold_to_blob(net), torch.from_numpy(x).float(), H, H, O, NB, 256)
     assert np.abs(mp.numpy() - p).max() <= 1e-2     # the two bf16 evaluations agree on the priors as well
     bound = min(1e-2 + 3.0 * np.abs(mv.numpy() - rv).max(), 1e-1)
-    print("value error %.2e (bound %.2e), priors error %.2e" % (ev, bound, ep))
+    print("  widened value bound %.2e" % bound)
     assert ev <= bound, (ev, bound)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-@pytest.mark.parametrize("game,H,NB,B", [("reversi", 8, 6, 3), ("go", 9, 10, 3), ("mnk", 15, 10, 2), ("go", 19, 20, 2)])
-def test_tower_at_named_depths(dtype, game, H, NB, B):
+DEPTHS = [("reversi", 8, 6, 3), ("go", 9, 10, 3), ("mnk", 15, 10, 2), ("go", 19, 20, 2)]
+
+
+@pytest.mark.parametrize("dtype,value_bound,game,H,NB,B",
+                         [("fp32", LITERAL) + d for d in DEPTHS] + [("f16", LITERAL) + d for d in DEPTHS] +
+                         [("bf16", LITERAL if d[2] <= 6 else WIDENED) + d for d in DEPTHS])
+def test_tower_at_named_depths(dtype, value_bound, game, H, NB, B):
     from alphazero_amd.engine import Engine
     from alphazero_amd.network.model import fold_to_blob
     O = H * H + (0 if game == "mnk" else 1)
@@ -235,23 +247,27 @@ def test_tower_at_named_depths(dtype, game, H, NB, B):
     eng.tower_load(fold_to_blob(net))
     x = _boards(B, H, H, seed=NB)
     p, v = eng.tower_forward(x)
-    _depth_check(p, v, net, NB, x, dtype, H, O)
+    _depth_check(p, v, net, NB, x, dtype, H, O, value_bound)
     eng.close()
 
 
-@pytest.mark.parametrize("game,H,NB,B", [("reversi", 8, 6, 520), ("go", 9, 10, 410), ("go", 19, 20, 96)])
-def test_full_tile_kernels_at_named_depths(game, H, NB, B):
-    """The same depths through the full-tile bf16 kernels (the batch sizes of self-play); three boards are checked."""
+FULL_TILE = [("reversi", 8, 6, 520), ("go", 9, 10, 410), ("go", 19, 20, 96)]
+
+
+@pytest.mark.parametrize("dtype,value_bound,game,H,NB,B",
+                         [("f16", LITERAL) + d for d in FULL_TILE] + [("bf16", LITERAL if d[2] <= 6 else WIDENED) + d for d in FULL_TILE])
+def test_full_tile_kernels_at_named_depths(dtype, value_bound, game, H, NB, B):
+    """The same depths through the full-tile 16-bit kernels (the batch sizes of self-play); three boards are checked."""
     from alphazero_amd.engine import Engine
     from alphazero_amd.network.model import fold_to_blob
     O = H * H + 1
     net = _deep_net(H, O, NB, seed=NB + 1)
-    eng = Engine(game, H, H, n_slots=B, num_blocks=NB, channels=256, tower_dtype="bf16")
+    eng = Engine(game, H, H, n_slots=B, num_blocks=NB, channels=256, tower_dtype=dtype)
     eng.tower_load(fold_to_blob(net))
     x = _boards(B, H, H, seed=NB + 1)
     p, v = eng.tower_forward(x)
     pick = np.array([0, B // 2, B - 1])
-    _depth_check(p[pick], v[pick], net, NB, x[pick], "bf16", H, O)
+    _depth_check(p[pick], v[pick], net, NB, x[pick], dtype, H, O, value_bound)
     eng.close()
 
 
@@ -304,7 +320,7 @@ def test_tower_forward_on_device_tensors():
     eng.close()
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "fp32"])
 def test_weights_loaded_from_device_memory_equal_the_host_load(dtype):
     """az_tower_load_weights_dev (padding, bf16 conversion and copies done by kernels on a blob in GPU memory, what the RCCL
     broadcast of a model update delivers) leaves the tower with the same weights as az_tower_load_weights from a host
