@@ -12,8 +12,10 @@ Positions: Go 19x19, slot g after 2 * (g % 32) uniformly random legal stone move
 engine.  Network: the bench's architecture (stem + `blocks` residual blocks x 256 channels), seeded random weights, batch-norm
 statistics calibrated on random boards as a trained network's are; `sharpen` multiplies the policy head's last layer (1 =
 flat priors of a random network, 30 = most of the mass on a few points, as after training).  Draws (transform ids, root
-noise, the move-choice uniform) are replayed, the same in every engine.  Writes a text summary to stdout and, with
-AZ_EFFECT_JSON=path, the numbers as JSON."""
+noise, the move-choice uniform) are replayed, the same in every engine.  Yardstick: the fp32 tower searched once more with
+OTHER transform ids (the reference draws a random dihedral transform for every playout, search/mcts.py:208, so this is
+how much two runs of the reference itself differ when nothing but those draws changes).  Writes a text summary to stdout
+and, with AZ_EFFECT_JSON=path, the numbers as JSON."""
 import json
 import os
 import sys
@@ -44,11 +46,12 @@ if SHARPEN != 1.0:
         net.p_fc.bias.mul_(SHARPEN)
 blob = fold_to_blob(net)
 
-names = ["fp32"] + DTYPES
+YARD = "fp32, other transform ids"
+names = ["fp32"] + DTYPES + [YARD]
 eng = {}
 for dt in names:
     eng[dt] = Engine("go", H, H, n_slots=G, max_playout=SIMS, transform_types=8, rng_replay=True, num_blocks=NB, channels=C,
-                     tower_dtype=dt, seed=1)
+                     tower_dtype="fp32" if dt == YARD else dt, seed=1)
     eng[dt].tower_load(blob)
 
 # positions: the same random legal stone moves in every engine
@@ -63,11 +66,15 @@ for t in range(int(n_plies.max())):
 # draws
 streams = [(rng.randint(0, 8, size=SIMS + 2).astype(np.int32), rng.gamma(0.03, 1.0, size=O), rng.rand(2)) for _ in range(G)]
 uni = rng.rand(G)
+other_tids = [rng.randint(0, 8, size=SIMS + 2).astype(np.int32) for _ in range(G)]
 res = {}
 for dt in names:
     e = eng[dt]
     for g in range(G):
-        e.rng_inject(g, *streams[g])
+        if dt == YARD:
+            e.rng_inject(g, other_tids[g], streams[g][1], streams[g][2])
+        else:
+            e.rng_inject(g, *streams[g])
     e.search_begin(np.arange(G), np.zeros(G, np.int32), np.ones(G, np.int32))
     t0 = time.perf_counter()
     e.search_run(SIMS + 1)
@@ -91,11 +98,11 @@ ref = res["fp32"]
 pmax = np.array([(r["n"] / r["n"].sum()).max() for r in ref["rows"]])
 print("  fp32 search: visit share of the most visited move: mean %.3f, max %.3f" % (pmax.mean(), pmax.max()))
 out["fp32_top_visit_share_mean"] = float(pmax.mean())
-for dt in DTYPES:
+for dt in DTYPES + [YARD]:
     cur = res[dt]
     d_pi, tv, arg, mv, dq, same_children = [], [], [], [], [], []
     for r0, r1 in zip(ref["rows"], cur["rows"]):
-        same = np.array_equal(r0["a"], r1["a"])
+        same = np.array_equal(np.sort(r0["a"]), np.sort(r1["a"]))   # (the order follows the root's transform id)
         same_children.append(same)
         pi0 = np.zeros(O); pi1 = np.zeros(O)
         pi0[r0["a"]] = r0["n"] / r0["n"].sum(); pi1[r1["a"]] = r1["n"] / r1["n"].sum()
