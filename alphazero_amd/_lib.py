@@ -30,6 +30,7 @@ class AzConfig(C.Structure):
         ("c_punt", C.c_double),
         ("tower_no_graphs", C.c_int32), ("tower_no_duo", C.c_int32), ("tower_group_boards", C.c_int32),
         ("match_parallel_towers", C.c_int32),
+        ("tree_pool_edges", C.c_int64), ("tree_page_edges", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -56,6 +57,8 @@ class AzCounters(C.Structure):
         ("expansions_skipped", C.c_uint64),
         ("peak_tree_edges", C.c_uint64), ("peak_tree_blocks", C.c_uint64),
         ("tree_edge_cap", C.c_uint64), ("tree_block_cap", C.c_uint64),
+        ("tree_page_edges", C.c_uint64), ("tree_pool_pages", C.c_uint64), ("tree_pool_pages_in_use", C.c_uint64),
+        ("tree_pool_pages_peak", C.c_uint64),
     ]
 
 

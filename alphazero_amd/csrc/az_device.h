@@ -98,7 +98,15 @@ struct Dev {
     void *values;        // R [G]
     // trees [2G]
     int32_t *rootN; void *rootW; void *rootP; int32_t *rootBlock; int32_t *nBlocks; int32_t *nEdges;   // rootW, rootP: R
-    int32_t *eN; void *eW; void *eP; int32_t *eChild; int16_t *eAct;       // [2G][EC]; eW, eP: R
+    // Edges live in pages of (1 << PS) edges that all trees of the engine draw from one pool: a tree addresses its edges
+    // 0 .. nEdges-1 as before (children of a node contiguous, blocks in creation order) and pt maps each page of that
+    // range to a page of the pool.  EC stays the most edges one tree may hold (the length of its page table).
+    int32_t *eN; void *eW; void *eP; int32_t *eChild; int16_t *eAct;       // [pool_pages << PS]; eW, eP: R
+    int PS, PTC, pool_pages;   // page shift; page-table entries per tree = ceil(EC / page); pages in the pool
+    int32_t *pt;               // [2G][PTC] pool page of each page of a tree (entries below nPages are valid)
+    int32_t *nPages;           // [2G] pages a tree holds: max(1, ceil(nEdges / page)); page 0 of tree t is pool page t for good
+    int32_t *pool_free;        // [pool_pages] stack of free pool pages
+    int32_t *pool_top;         // [0] free pages on the stack; [1] the lowest [0] has been since the counters were reset
     int32_t *bStart, *bCount, *bOwner, *bParent, *bMap, *bShift;             // [2G][BC]
     int32_t *pending;    // [2G] move to re-root with, NOMOVE = none
     // rng
@@ -138,6 +146,81 @@ __device__ __forceinline__ SK slot_sk(const Dev &D, int g)
 // ---------------------------------------------------------------------------
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// ---------------------------------------------------------------------------
+// paged tree edges
+// ---------------------------------------------------------------------------
+
+// pool index of edge v of tree t
+__device__ __forceinline__ size_t edge_at(const Dev &D, int t, int v)
+{
+    return ((size_t)D.pt[(size_t)t * D.PTC + (v >> D.PS)] << D.PS) | (size_t)(v & ((1 << D.PS) - 1));
+}
+
+// The children of one node are contiguous in the tree's own numbering and never more than a page (a page holds at least
+// as many edges as the game has actions), so they touch at most two pages: both are looked up once.
+struct Span {
+    size_t b0, b1;
+    int pg0, sh, mask;
+    __device__ __forceinline__ size_t at(int v) const { return ((v >> sh) == pg0 ? b0 : b1) + (size_t)(v & mask); }
+};
+
+__device__ __forceinline__ Span span_of(const Dev &D, int t, int start)
+{
+    Span s;
+    s.sh = D.PS; s.mask = (1 << D.PS) - 1; s.pg0 = start >> D.PS;
+    const int32_t *pt = D.pt + (size_t)t * D.PTC;
+    s.b0 = (size_t)pt[min(s.pg0, D.PTC - 1)] << D.PS;
+    s.b1 = (size_t)pt[min(s.pg0 + 1, D.PTC - 1)] << D.PS;   // (read even when the tree does not hold that page: never used then)
+    return s;
+}
+
+// Makes tree t hold the pages its first n_edges edges need; called by every lane, lane 0 takes pages off the pool's free
+// stack.  Returns 0 when the pool has too few pages left (nothing is taken then).  Only kernels that never give pages
+// back may call this: the stack's entries below its top were written by earlier launches.
+__device__ __forceinline__ int tree_reserve(const Dev &D, int t, int n_edges)
+{
+    const int need = (n_edges + (1 << D.PS) - 1) >> D.PS;
+    const int have = D.nPages[t];
+    if (need <= have) return 1;
+    int ok = 1;
+    if (lane_id() == 0) {
+        const int k = need - have;
+        const int top = atomicSub(&D.pool_top[0], k);
+        if (top < k) {
+            atomicAdd(&D.pool_top[0], k);
+            ok = 0;
+        } else {
+            int32_t *pt = D.pt + (size_t)t * D.PTC;
+            for (int i = 0; i < k; i++) pt[have + i] = D.pool_free[top - k + i];
+            D.nPages[t] = need;
+            if (top - k < D.pool_top[1]) atomicMin(&D.pool_top[1], top - k);
+        }
+    }
+    ok = __shfl(ok, 0, 64);
+    WSYNC();
+    return ok;
+}
+
+// Tree t keeps its first `keep` pages and hands the others back to the pool.  Its first page is its own for good (pool
+// page t): the children of a root always have a place, however empty the pool is.  Only kernels that never take pages
+// may call this (the top moves before the entries are written).
+__device__ __forceinline__ void tree_release(const Dev &D, int t, int keep)
+{
+    if (keep < 1) keep = 1;
+    const int have = D.nPages[t];
+    WSYNC();
+    if (have <= keep) return;
+    const int k = have - keep;
+    int base = 0;
+    if (lane_id() == 0) base = atomicAdd(&D.pool_top[0], k);
+    base = __shfl(base, 0, 64);
+    const int32_t *pt = D.pt + (size_t)t * D.PTC;
+    for (int i = lane_id(); i < k; i += AZ_WAVE) D.pool_free[base + i] = pt[keep + i];
+    if (lane_id() == 0) D.nPages[t] = keep;
+    WSYNC();
+}
+
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z)
 {

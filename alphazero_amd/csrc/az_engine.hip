@@ -98,7 +98,7 @@ static int set_err(az_engine *h, int code, const char *msg)
 static const char *err_text(int code)
 {
     switch (code) {
-    case AZ_ERR_TREE_FULL: return "tree arena full (raise tree_edge_cap / tree_block_cap)";
+    case AZ_ERR_TREE_FULL: return "tree full: tree_edge_cap / tree_block_cap reached, or the shared edge pool (tree_pool_edges) has no page left";
     case AZ_ERR_RNG_UNDERFLOW: return "RNG replay stream underflow";
     case AZ_ERR_DEPTH: return "playout deeper than max_depth";
     case AZ_ERR_STATE: return "search finished without a legal move";
@@ -122,42 +122,80 @@ static int check_slot_errors(az_engine *h)
     return AZ_OK;
 }
 
-// Enlarges the arenas of every tree to new_ec edges / new_bc expanded nodes (never shrinks): new arrays, each tree's
-// old stride copied to the front of its new one, old arrays freed.  The stream is idle on entry and on return.
-static int grow_trees(az_engine *h, long long new_ec, long long new_bc)
+// Fills the free stack of the edge pool with pages first .. first + n - 1 at positions at .. at + n - 1, highest page
+// lowest, so that low pages are handed out first.
+__global__ void k_pool_fill(int32_t *__restrict__ stack, int at, int first, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) stack[at + i] = first + n - 1 - i;
+}
+
+// Every tree's first page is pool page t, for good.
+__global__ void k_pool_home(Dev D)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 2 * D.G) { D.pt[(size_t)t * D.PTC] = t; D.nPages[t] = 1; }
+}
+
+// Raises the limits of every tree to new_ec edges / new_bc expanded nodes and the edge pool to new_pages pages (nothing
+// ever shrinks): new arrays, old contents copied to their front (a tree's page table and block table keep their row, a
+// pool page keeps its number), the added pages pushed on the free stack, old arrays freed.  All new arrays are
+// allocated and filled before anything of the engine changes: a failed allocation or copy leaves trees, limits and pool
+// exactly as they were.  The stream is idle on entry and on return.
+static int grow_trees(az_engine *h, long long new_ec, long long new_bc, long long new_pages)
 {
     Dev &D = h->D;
     if (new_ec < D.EC) new_ec = D.EC;
     if (new_bc < D.BC) new_bc = D.BC;
-    if (new_ec > 0x7fffffffLL || new_bc > 0x7fffffffLL) return set_err(h, AZ_ERR_ARG, "tree caps too large");
-    if (new_ec == D.EC && new_bc == D.BC) return AZ_OK;
+    if (new_pages < D.pool_pages) new_pages = D.pool_pages;
+    const long long page = 1LL << D.PS;
+    const long long new_ptc = (new_ec + page - 1) / page;
+    if (new_ec > 0x7fffffffLL || new_bc > 0x7fffffffLL || new_pages > 0x7fffffffLL) return set_err(h, AZ_ERR_ARG, "tree caps too large");
+    if (new_ec == D.EC && new_bc == D.BC && new_pages == D.pool_pages) return AZ_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
     const size_t T = 2 * (size_t)D.G, rs = D.f64 ? 8 : 4;
-    struct Arr { void **p; size_t elem; bool edge; };
+    // kind 0: per-tree rows of BC entries; 1: per-tree rows of PTC entries; 2: one row of pool_pages << PS edges;
+    // 3: one row of pool_pages entries (the free stack)
+    struct Arr { void **p; size_t elem; int kind; };
     Arr arrs[] = {
-        {(void **)&D.eN, 4, true}, {&D.eW, rs, true}, {&D.eP, rs, true}, {(void **)&D.eChild, 4, true}, {(void **)&D.eAct, 2, true},
-        {(void **)&D.bStart, 4, false}, {(void **)&D.bCount, 4, false}, {(void **)&D.bOwner, 4, false},
-        {(void **)&D.bParent, 4, false}, {(void **)&D.bMap, 4, false}, {(void **)&D.bShift, 4, false},
+        {(void **)&D.eN, 4, 2}, {&D.eW, rs, 2}, {&D.eP, rs, 2}, {(void **)&D.eChild, 4, 2}, {(void **)&D.eAct, 2, 2},
+        {(void **)&D.bStart, 4, 0}, {(void **)&D.bCount, 4, 0}, {(void **)&D.bOwner, 4, 0},
+        {(void **)&D.bParent, 4, 0}, {(void **)&D.bMap, 4, 0}, {(void **)&D.bShift, 4, 0},
+        {(void **)&D.pt, 4, 1}, {(void **)&D.pool_free, 4, 3},
     };
-    // all new arrays are allocated and filled before anything of the engine changes: a failed allocation or copy leaves the
-    // old arenas, their strides and the trees in them exactly as they were
     constexpr int NA = sizeof(arrs) / sizeof(arrs[0]);
     void *fresh[NA] = {};
     auto undo = [&]() { for (void *q : fresh) if (q) hipFree(q); };
     for (int i = 0; i < NA; i++) {
         const Arr &a = arrs[i];
-        const size_t oc = a.edge ? (size_t)D.EC : (size_t)D.BC, nc = a.edge ? (size_t)new_ec : (size_t)new_bc;
+        size_t rows = T, oc, nc;
+        switch (a.kind) {
+        case 0: oc = (size_t)D.BC; nc = (size_t)new_bc; break;
+        case 1: oc = (size_t)D.PTC; nc = (size_t)new_ptc; break;
+        case 2: rows = 1; oc = (size_t)D.pool_pages << D.PS; nc = (size_t)new_pages << D.PS; break;
+        default: rows = 1; oc = (size_t)D.pool_pages; nc = (size_t)new_pages; break;
+        }
         if (oc == nc) continue;
-        if (hipMalloc(&fresh[i], T * nc * a.elem) != hipSuccess) {
+        if (hipMalloc(&fresh[i], rows * nc * a.elem) != hipSuccess) {
             (void)hipGetLastError();
             undo();
-            return set_err(h, AZ_ERR_HIP, "device allocation failed while enlarging the tree arenas (the trees are unchanged)");
+            return set_err(h, AZ_ERR_HIP, "device allocation failed while enlarging the trees (they are unchanged)");
         }
-        const hipError_t e = hipMemcpy2D(fresh[i], nc * a.elem, *a.p, oc * a.elem, oc * a.elem, T, hipMemcpyDeviceToDevice);
+        const hipError_t e = rows == 1 ? hipMemcpy(fresh[i], *a.p, oc * a.elem, hipMemcpyDeviceToDevice)
+                                       : hipMemcpy2D(fresh[i], nc * a.elem, *a.p, oc * a.elem, oc * a.elem, rows, hipMemcpyDeviceToDevice);
         if (e != hipSuccess) {
             undo();
-            h->error = std::string("copy into the enlarged tree arenas failed (the trees are unchanged): ") + hipGetErrorString(e);
+            h->error = std::string("copy while enlarging the trees failed (they are unchanged): ") + hipGetErrorString(e);
             return AZ_ERR_HIP;
+        }
+    }
+    const int added = (int)(new_pages - D.pool_pages);
+    int32_t top[2] = {0, 0};
+    if (added > 0) {
+        const hipError_t e = hipMemcpy(top, D.pool_top, sizeof top, hipMemcpyDeviceToHost);
+        if (e != hipSuccess || top[0] < 0 || top[0] > D.pool_pages) {
+            undo();
+            return set_err(h, AZ_ERR_HIP, "reading the edge pool's free count failed (the trees are unchanged)");
         }
     }
     for (int i = 0; i < NA; i++) {
@@ -167,20 +205,27 @@ static int grow_trees(az_engine *h, long long new_ec, long long new_bc)
         hipFree(*arrs[i].p);
         *arrs[i].p = fresh[i];
     }
-    D.EC = (int)new_ec; D.BC = (int)new_bc;
+    if (added > 0) {
+        // the new pages go on top of the free stack; the low-water mark moves with the top, so the peak (pages in use) stays
+        hipLaunchKernelGGL(k_pool_fill, dim3((added + 255) / 256), dim3(256), 0, h->stream, D.pool_free, top[0], D.pool_pages, added);
+        top[0] += added; top[1] += added;
+        HIPCHK(hipMemcpyAsync(D.pool_top, top, sizeof top, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    D.EC = (int)new_ec; D.BC = (int)new_bc; D.PTC = (int)new_ptc; D.pool_pages = (int)new_pages;
     return AZ_OK;
 }
 
 static void launch_tail(az_engine *h);
 static int check_slot_errors(az_engine *h);
 
-// tree_full_policy 2: slots stopped by a full arena get arenas twice the size and their pending playout is completed
+// tree_full_policy 2: a slot stopped by a full tree or an empty pool doubles the trees' limits and the pool, and its pending playout is completed
 // (their leaf, path and - for the tower - the same planes are still in place).  selfplay: also play due moves.
 static int check_and_grow(az_engine *h, bool selfplay)
 {
     int rc = check_slot_errors(h);
     for (int tries = 0; rc == AZ_ERR_TREE_FULL && h->cfg.tree_full_policy == 2 && tries < 8; tries++) {
-        if ((rc = grow_trees(h, 2LL * h->D.EC, 2LL * h->D.BC))) return rc;
+        if ((rc = grow_trees(h, 2LL * h->D.EC, 2LL * h->D.BC, 2LL * h->D.pool_pages))) return rc;
         h->error.clear();
         hipLaunchKernelGGL(k_clear_tree_full, dim3((h->D.G + 255) / 256), dim3(256), 0, h->stream, h->D);
         if (selfplay) launch_tail(h);
@@ -195,7 +240,10 @@ extern "C" int az_search_grow_trees(az_engine *h, int32_t edge_cap, int32_t bloc
 {
     if (!h || edge_cap < 0 || block_cap < 0) return AZ_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device));
-    return grow_trees(h, edge_cap ? edge_cap : 2LL * h->D.EC, block_cap ? block_cap : 2LL * h->D.BC);
+    const long long ec = std::max<long long>(edge_cap ? edge_cap : 2LL * h->D.EC, h->D.EC);
+    // the pool grows by the factor the per-tree limit grows by
+    const long long pages = (long long)(((__int128)h->D.pool_pages * ec + h->D.EC - 1) / h->D.EC);
+    return grow_trees(h, ec, block_cap ? block_cap : 2LL * h->D.BC, pages);
 }
 
 extern "C" const char *az_last_error(az_engine *h) { return h ? h->error.c_str() : g_create_error.c_str(); }
@@ -298,6 +346,30 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     if (bc < 2) bc = 2;
     if (ec > 0x7fffffffLL || bc > 0x7fffffffLL) { g_create_error = "tree caps too large"; delete h; return nullptr; }
     D.EC = (int)ec; D.BC = (int)bc;
+    {
+        // pages of the shared edge pool: a power of two, at least the number of actions (a node's children then touch at
+        // most two pages)
+        int o2 = 1, ps = 0;
+        while (o2 < O) o2 <<= 1;
+        long long page = cfg->tree_page_edges > 0 ? cfg->tree_page_edges : std::max(64, 4 * o2);
+        if ((page & (page - 1)) != 0 || page < o2 || page > (1 << 24)) {
+            g_create_error = "tree_page_edges must be a power of two, at least the number of actions and at most 2^24";
+            delete h; return nullptr;
+        }
+        while ((1LL << ps) < page) ps++;
+        D.PS = ps;
+        D.PTC = (int)((ec + page - 1) / page);
+        const long long T2 = 2LL * cfg->n_slots;
+        long long pool_edges = cfg->tree_pool_edges;
+        if (pool_edges < 0) { g_create_error = "tree_pool_edges must not be negative"; delete h; return nullptr; }
+        long long pages = pool_edges > 0 ? (pool_edges + page - 1) / page
+                          : (cfg->tree_edge_cap > 0 ? T2 * D.PTC : (T2 * ec / 2 + page - 1) / page);
+        // every tree owns one page for good (a root's children always have a place)
+        pages = std::max(pages, T2);
+        pages = std::min(pages, T2 * D.PTC);
+        if (pages > 0x7fffffffLL) { g_create_error = "tree pool too large"; delete h; return nullptr; }
+        D.pool_pages = (int)pages;
+    }
     D.MAXD = cfg->max_depth > 0 ? cfg->max_depth : 1024;
     D.rng_replay = cfg->rng_replay; D.seed = cfg->seed;
     D.record = cfg->record_trajectories;
@@ -331,8 +403,10 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
     const size_t T = 2 * (size_t)G;
     A(rootN, int32_t, T); AR(rootW, T); AR(rootP, T); A(rootBlock, int32_t, T);
     A(nBlocks, int32_t, T); A(nEdges, int32_t, T); A(pending, int32_t, T);
-    A(eN, int32_t, T * D.EC); AR(eW, T * D.EC); AR(eP, T * D.EC);
-    A(eChild, int32_t, T * D.EC); A(eAct, int16_t, T * D.EC);
+    const size_t PE = (size_t)D.pool_pages << D.PS;   // edges in the pool
+    A(eN, int32_t, PE); AR(eW, PE); AR(eP, PE);
+    A(eChild, int32_t, PE); A(eAct, int16_t, PE);
+    A(pt, int32_t, T * D.PTC); A(nPages, int32_t, T); A(pool_free, int32_t, D.pool_pages); A(pool_top, int32_t, 2);
     A(bStart, int32_t, T * D.BC); A(bCount, int32_t, T * D.BC); A(bOwner, int32_t, T * D.BC);
     A(bParent, int32_t, T * D.BC); A(bMap, int32_t, T * D.BC); A(bShift, int32_t, T * D.BC);
     A(rt, const int32_t *, G); A(rt_n, long long, G); A(rt_i, long long, G);
@@ -370,6 +444,15 @@ extern "C" az_engine *az_engine_create(const az_config *cfg)
         h->tower = tower_create(H, W, O, cfg->num_blocks, cfg->channels > 0 ? cfg->channels : 256, cfg->tower_dtype, D.K * G,
                                 tower_options(*cfg), terr);
         if (!h->tower) { g_create_error = "tower: " + terr; az_engine_destroy(h); return nullptr; }
+    }
+    {
+        // pages 0 .. 2G-1 are the trees' own first pages, the others start on the free stack
+        const int T2 = 2 * G, nfree = D.pool_pages - T2;
+        const int32_t top[2] = {nfree, nfree};
+        hipLaunchKernelGGL(k_pool_home, dim3((T2 + 255) / 256), dim3(256), 0, h->stream, D);
+        if (nfree > 0) hipLaunchKernelGGL(k_pool_fill, dim3((nfree + 255) / 256), dim3(256), 0, h->stream, D.pool_free, 0, T2, nfree);
+        (void)hipMemcpyAsync(D.pool_top, top, sizeof top, hipMemcpyHostToDevice, h->stream);
+        (void)hipStreamSynchronize(h->stream);   // (top is a stack variable)
     }
     hipLaunchKernelGGL(k_reset, dim3(G), dim3(64), 0, h->stream, D, (const int32_t *)nullptr, G, 0);
     if (hipStreamSynchronize(h->stream) != hipSuccess) {
@@ -409,6 +492,13 @@ extern "C" int az_games_reset(az_engine *h, const int32_t *slots, int32_t n)
     int rc = check_slots(h, slots, n);
     if (rc) return rc;
     if (n == 0) return AZ_OK;
+    {   // one workgroup per listed slot gives the slot's tree pages back: a slot listed twice would give them back twice
+        std::vector<char> seen(h->D.G, 0);
+        for (int i = 0; i < n; i++) {
+            if (seen[slots[i]]) return set_err(h, AZ_ERR_ARG, "duplicate slot in one reset");
+            seen[slots[i]] = 1;
+        }
+    }
     HIPCHK(hipSetDevice(h->cfg.device));
     if ((rc = up(h, h->st_a, slots, n))) return rc;
     hipLaunchKernelGGL(k_reset, dim3(n), dim3(64), 0, h->stream, h->D, (const int32_t *)h->st_a, n, 0);
@@ -796,15 +886,23 @@ static int root_stats(az_engine *h, int32_t slot, int32_t side, int32_t *actions
     int32_t start = 0, n = 0;
     HIPCHK(hipMemcpy(&start, D.bStart + (size_t)t * D.BC + rb, 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&n, D.bCount + (size_t)t * D.BC + rb, 4, hipMemcpyDeviceToHost));
-    const size_t e0 = (size_t)t * D.EC + start;
-    if (visits) HIPCHK(hipMemcpy(visits, D.eN + e0, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-    if (total_value) HIPCHK(hipMemcpy(total_value, (const char *)D.eW + e0 * rs, rs * n, hipMemcpyDeviceToHost));
-    if (prior) HIPCHK(hipMemcpy(prior, (const char *)D.eP + e0 * rs, rs * n, hipMemcpyDeviceToHost));
-    if (actions) {
-        std::vector<int16_t> a(n);
-        HIPCHK(hipMemcpy(a.data(), D.eAct + e0, sizeof(int16_t) * n, hipMemcpyDeviceToHost));
-        for (int i = 0; i < n; i++) actions[i] = a[i];
+    if (n <= 0) return 0;
+    // the children are contiguous in the tree's own numbering; every page of that range is copied from where the tree's
+    // page table says it lies in the pool
+    const int page = 1 << D.PS, pg0 = start >> D.PS, pg1 = (start + n - 1) >> D.PS;
+    std::vector<int32_t> pages(pg1 - pg0 + 1);
+    HIPCHK(hipMemcpy(pages.data(), D.pt + (size_t)t * D.PTC + pg0, sizeof(int32_t) * pages.size(), hipMemcpyDeviceToHost));
+    std::vector<int16_t> a(actions ? n : 0);
+    for (int pg = pg0; pg <= pg1; pg++) {
+        const int v0 = std::max(start, pg * page), v1 = std::min(start + n, (pg + 1) * page);   // [v0, v1) of the tree
+        const size_t e0 = ((size_t)pages[pg - pg0] << D.PS) + (size_t)(v0 - pg * page), o = (size_t)(v0 - start), k = (size_t)(v1 - v0);
+        if (pages[pg - pg0] < 0 || pages[pg - pg0] >= D.pool_pages) return set_err(h, AZ_ERR_HIP, "tree page table holds a page outside the pool");
+        if (visits) HIPCHK(hipMemcpy(visits + o, D.eN + e0, sizeof(int32_t) * k, hipMemcpyDeviceToHost));
+        if (total_value) HIPCHK(hipMemcpy((char *)total_value + o * rs, (const char *)D.eW + e0 * rs, rs * k, hipMemcpyDeviceToHost));
+        if (prior) HIPCHK(hipMemcpy((char *)prior + o * rs, (const char *)D.eP + e0 * rs, rs * k, hipMemcpyDeviceToHost));
+        if (actions) HIPCHK(hipMemcpy(a.data() + o, D.eAct + e0, sizeof(int16_t) * k, hipMemcpyDeviceToHost));
     }
+    for (int i = 0; i < (int)a.size(); i++) actions[i] = a[i];
     return n;
 }
 
@@ -1421,6 +1519,10 @@ extern "C" int az_counters_get(az_engine *h, az_counters *out)
         for (int b = 0; b < AZ_CTR_BUCKETS; b++) { pe = std::max(pe, pk[2 * b]); pb = std::max(pb, pk[2 * b + 1]); }
         out->peak_tree_edges = pe; out->peak_tree_blocks = pb;
         out->tree_edge_cap = h->D.EC; out->tree_block_cap = h->D.BC;
+        int32_t top[2];
+        HIPCHK(hipMemcpy(top, h->D.pool_top, sizeof top, hipMemcpyDeviceToHost));
+        out->tree_page_edges = 1ull << h->D.PS; out->tree_pool_pages = h->D.pool_pages;
+        out->tree_pool_pages_in_use = h->D.pool_pages - top[0]; out->tree_pool_pages_peak = h->D.pool_pages - top[1];
     }
     out->conv_ms = 0; out->conv_launches = 0; out->conv_flops_per_launch = 0;
     if (h->tower) {
@@ -1443,6 +1545,7 @@ extern "C" int az_counters_reset(az_engine *h)
     h->tower_calls = h->tower_evals = h->steps = 0;
     HIPCHK(hipMemset(h->net_tot, 0, 2 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(h->D.peak, 0, sizeof(int32_t) * AZ_CTR_BUCKETS * 2));
+    HIPCHK(hipMemcpy(h->D.pool_top + 1, h->D.pool_top, sizeof(int32_t), hipMemcpyDeviceToDevice));   // peak restarts at the present use
     if (h->tower) { double a, c; unsigned long long b; tower_profile_read(h->tower, &a, &b, &c, true); }
     return AZ_OK;
 }

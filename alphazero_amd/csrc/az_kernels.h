@@ -88,8 +88,9 @@ __device__ void apply_noise(const Dev &D, int g, int t)
     const int lane = lane_id();
     int rb = D.rootBlock[t];
     if (rb < 0) return;
-    size_t tb = (size_t)t * D.EC, bb = (size_t)t * D.BC;
+    size_t bb = (size_t)t * D.BC;
     int start = D.bStart[bb + rb], n = D.bCount[bb + rb];
+    const Span sp = span_of(D, t, start);
     R keep = (R)(1.0 - D.d_epsilon);
     long long base = 0;
     unsigned long long key = 0;
@@ -103,9 +104,9 @@ __device__ void apply_noise(const Dev &D, int g, int t)
     }
     for (int c = lane; c < n; c += AZ_WAVE) {
         double eta = D.rng_replay ? D.re[g][base + c] : gamma_variate(D.d_alpha, key + 1000ULL * (unsigned long long)(c + 1));
-        R p = eP[tb + start + c];
+        R p = eP[sp.at(start + c)];
         R a = keep * p;
-        eP[tb + start + c] = a + (R)(D.d_epsilon * eta);
+        eP[sp.at(start + c)] = a + (R)(D.d_epsilon * eta);
     }
     WSYNC();
 }
@@ -161,7 +162,7 @@ __device__ __forceinline__ void select_one(const Dev &D, const int sub, WLds &L)
     if (sub > 0 && (phase != PH_IN_SEARCH || D.issued[g] >= D.max_playout)) return;
     const int side = D.side[g];
     const int t = 2 * g + side;
-    const size_t tb = (size_t)t * D.EC, bb = (size_t)t * D.BC;
+    const size_t bb = (size_t)t * D.BC;
 
     PS s;
     load_scalars(D, g, s);
@@ -199,6 +200,7 @@ __device__ __forceinline__ void select_one(const Dev &D, const int sub, WLds &L)
         SEL_STAMP(1);  // search start / noise
         while (blk >= 0) {
             int start = D.bStart[bb + blk], n = D.bCount[bb + blk];
+            const Span sp = span_of(D, t, start);
             // Q+U in the evaluator's precision, left to right as mcts.py:88-90; first maximum wins.  A node has at most
             // AZ_NJ * 64 children: all their statistics are requested before any is used (one memory latency per level,
             // not one per 64 children); a slot past the end re-reads the last child and is ignored.
@@ -208,7 +210,7 @@ __device__ __forceinline__ void select_one(const Dev &D, const int sub, WLds &L)
             R cW[AZ_NJ], cP[AZ_NJ];
 #pragma unroll
             for (int j = 0; j < AZ_NJ; j++) {
-                const size_t ci = tb + start + min(lane + j * AZ_WAVE, n - 1);
+                const size_t ci = sp.at(start + min(lane + j * AZ_WAVE, n - 1));
                 cN[j] = D.eN[ci]; cW[j] = eW[ci]; cP[j] = eP[ci];
             }
             R bv = -INFINITY;
@@ -225,7 +227,7 @@ __device__ __forceinline__ void select_one(const Dev &D, const int sub, WLds &L)
                 if (c < n && v > bv) { bv = v; bi = c; bN = N; }
             }
             // the action and the child block of this lane's own best candidate are fetched while the lanes compare
-            const size_t mine = tb + start + (bi == 0x7fffffff ? min(lane, n - 1) : bi);
+            const size_t mine = sp.at(start + (bi == 0x7fffffff ? min(lane, n - 1) : bi));
             if (bi == 0x7fffffff) bN = cN[0];
             const int myAct = D.eAct[mine], myChild = D.eChild[mine];
 #pragma unroll
@@ -251,8 +253,8 @@ __device__ __forceinline__ void select_one(const Dev &D, const int sub, WLds &L)
             int N = __shfl(bN, wl, 64) + 1;  // child.visit()
             WSYNC();
             if (lane == 0) {
-                D.eN[tb + e] = N;
-                if (D.K > 1) eW[tb + e] -= (R)D.vloss;  // virtual loss, taken back by k_finish
+                D.eN[sp.at(e)] = N;
+                if (D.K > 1) eW[sp.at(e)] -= (R)D.vloss;  // virtual loss, taken back by k_finish
             }
             node = e; node_block = blk;
             parentN = N;
@@ -336,9 +338,10 @@ __device__ __forceinline__ int finish_one(const Dev &D, const int sub)
     if (!D.leaf_valid[li] || D.err[g] != 0) return 0;
     const int side = D.side[g];
     const int t = 2 * g + side;
-    const size_t tb = (size_t)t * D.EC, bb = (size_t)t * D.BC;
+    const size_t bb = (size_t)t * D.BC;
     const int root_expand = D.leaf_root[li];
     const int node = D.leaf_node[li];
+    const size_t en = node == NODE_ROOT ? 0 : edge_at(D, t, node);   // the leaf's own edge
     const int player = D.leaf_player[li];
     const int tid = D.leaf_tid[li];
     R v = static_cast<const R *>(D.values)[li];
@@ -347,12 +350,12 @@ __device__ __forceinline__ int finish_one(const Dev &D, const int sub)
     const R vl = D.K > 1 ? (R)D.vloss : (R)0.0;
     WSYNC();
     // with several leaves in flight an earlier sub-round of this round may already have expanded the node
-    const int has_children = D.K > 1 && (node == NODE_ROOT ? D.rootBlock[t] >= 0 : D.eChild[tb + node] >= 0);
+    const int has_children = D.K > 1 && (node == NODE_ROOT ? D.rootBlock[t] >= 0 : D.eChild[en] >= 0);
     const int expandable = root_expand ? 1 : !D.leaf_end[li];
     if (expandable && has_children) {
         if (lane == 0) {
             R add = (R)(-player) * v;
-            if (node == NODE_ROOT) rootW[t] += add; else eW[tb + node] += add + vl;
+            if (node == NODE_ROOT) rootW[t] += add; else eW[en] += add + vl;
         }
     } else if (expandable) {
         int bi = D.nBlocks[t], start = D.nEdges[t];
@@ -369,8 +372,11 @@ __device__ __forceinline__ int finish_one(const Dev &D, const int sub)
         }
         // a full arena is an error, or (tree_full_policy 1, never at a root) the node simply stays a leaf for this
         // playout: its value is backed up as usual and the event is counted
-        const int full = (bi >= D.BC || start + n > D.EC);
+        // (the tree's own limits first; then the pages the new children need, which the shared pool may not have)
+        int full = (bi >= D.BC || start + n > D.EC);
+        if (!full && n > 0 && !tree_reserve(D, t, start + n)) full = 1;
         if (full && (D.full_policy != 1 || root_expand)) { if (lane == 0) D.err[g] = -4; return 0; }
+        const Span sp = span_of(D, t, start);
         int off = 0;
         for (int i0 = 0; i0 < G.O && !full; i0 += AZ_WAVE) {
             int i = i0 + lane;
@@ -382,7 +388,7 @@ __device__ __forceinline__ int finish_one(const Dev &D, const int sub)
             unsigned long long bal = __ballot(legal);
             int pos = off + __popcll(bal & ((1ULL << lane) - 1ULL));
             if (legal) {
-                size_t e = tb + start + pos;
+                size_t e = sp.at(start + pos);
                 D.eN[e] = 0; eW[e] = (R)0.0; eP[e] = pri[i]; D.eChild[e] = -1; D.eAct[e] = (int16_t)a;
             }
             off += __popcll(bal);
@@ -396,18 +402,18 @@ __device__ __forceinline__ int finish_one(const Dev &D, const int sub)
                 int32_t *pk = D.peak + 2 * (blockIdx.x & (AZ_CTR_BUCKETS - 1));
                 if (start + n > pk[0]) atomicMax(&pk[0], start + n);
                 if (bi + 1 > pk[1]) atomicMax(&pk[1], bi + 1);
-                if (node == NODE_ROOT) D.rootBlock[t] = bi; else D.eChild[tb + node] = bi;
+                if (node == NODE_ROOT) D.rootBlock[t] = bi; else D.eChild[en] = bi;
                 atomicAdd(&D.ctr[(size_t)(blockIdx.x & (AZ_CTR_BUCKETS - 1)) * C_N + C_EDGES], (unsigned long long)n);
             }
             // node.update(value): raw value at the root, -player*value below it
             R add = root_expand ? v : (R)(-player) * v;
-            if (node == NODE_ROOT) rootW[t] += add; else eW[tb + node] += add + vl;
+            if (node == NODE_ROOT) rootW[t] += add; else eW[en] += add + vl;
         }
     } else {
         v = (R)D.leaf_winner[li];  // value = state.get_winner()
         if (lane == 0) {
             R add = (R)(-player) * v;
-            if (node == NODE_ROOT) rootW[t] += add; else eW[tb + node] += add + vl;
+            if (node == NODE_ROOT) rootW[t] += add; else eW[en] += add + vl;
         }
     }
     WSYNC();
@@ -424,7 +430,7 @@ __device__ __forceinline__ int finish_one(const Dev &D, const int sub)
     for (int d = lane; d < plen; d += AZ_WAVE) {
         int nd = D.path_node[(size_t)li * D.MAXD + d];
         R add = (R)(-(int)D.path_player[(size_t)li * D.MAXD + d]) * v;
-        if (nd == NODE_ROOT) rootW[t] += add; else eW[tb + nd] += add + vl;
+        if (nd == NODE_ROOT) rootW[t] += add; else eW[edge_at(D, t, nd)] += add + vl;
     }
     if (lane == 0) {
         int pd = D.pdone[g] + 1;
@@ -457,12 +463,13 @@ __global__ __launch_bounds__(64) void k_finish(Dev D, int sub)
 __device__ int dev_choose(const Dev &D, WLds &L, int t, double u, int *n_out)
 {
     const int lane = lane_id();
-    size_t tb = (size_t)t * D.EC, bb = (size_t)t * D.BC;
+    size_t bb = (size_t)t * D.BC;
     int rb = D.rootBlock[t];
     if (rb < 0) { *n_out = 0; return NOMOVE; }
     int start = D.bStart[bb + rb], n = D.bCount[bb + rb];
+    const Span sp = span_of(D, t, start);
     *n_out = n;
-    for (int c = lane; c < n; c += AZ_WAVE) L.libs[c] = D.eN[tb + start + c];
+    for (int c = lane; c < n; c += AZ_WAVE) L.libs[c] = D.eN[sp.at(start + c)];
     WSYNC();
     if (lane == 0) {
         long long total = 0;
@@ -484,7 +491,7 @@ __device__ int dev_choose(const Dev &D, WLds &L, int t, double u, int *n_out)
     WSYNC();
     int idx = L.tmp[0];
     WSYNC();
-    return D.eAct[tb + start + idx];
+    return D.eAct[sp.at(start + idx)];
 }
 
 // one ply of Game.start for every slot whose search is complete
@@ -498,7 +505,7 @@ __global__ __launch_bounds__(64) void k_move(Dev D)
     if (D.phase[g] != PH_SEARCH_DONE || !D.automode[g] || D.err[g] != 0) return;
     const int side = D.side[g];
     const int t = 2 * g + side;
-    const size_t tb = (size_t)t * D.EC, bb = (size_t)t * D.BC;
+    const size_t bb = (size_t)t * D.BC;
     double u = rng_uniform(D, g);
     int n = 0;
     int mv = dev_choose(D, L, t, u, &n);
@@ -509,7 +516,8 @@ __global__ __launch_bounds__(64) void k_move(Dev D)
         for (int i = lane; i < G.O; i += AZ_WAVE) row[i] = 0;
         WSYNC();
         int start = D.bStart[bb + D.rootBlock[t]];
-        for (int c = lane; c < n; c += AZ_WAVE) row[D.eAct[tb + start + c]] = D.eN[tb + start + c];
+        const Span sp = span_of(D, t, start);
+        for (int c = lane; c < n; c += AZ_WAVE) row[D.eAct[sp.at(start + c)]] = D.eN[sp.at(start + c)];
         if (lane == 0) D.tr_moves[(size_t)g * D.traj_plies + ply] = (int16_t)mv;
     }
     PS s;
@@ -558,14 +566,15 @@ __global__ __launch_bounds__(64) void k_reroot(Dev D)
     if (mv == NOMOVE) return;
     WSYNC();
     if (lane == 0) D.pending[t] = NOMOVE;
-    const size_t tb = (size_t)t * D.EC, bb = (size_t)t * D.BC;
+    const size_t bb = (size_t)t * D.BC;
     const int rb = D.rootBlock[t];
     int found = -1;
     if (rb >= 0) {
         int start = D.bStart[bb + rb], n = D.bCount[bb + rb];
+        const Span sp = span_of(D, t, start);
         for (int c0 = 0; c0 < n; c0 += AZ_WAVE) {
             int c = c0 + lane;
-            int hit = (c < n) && (D.eAct[tb + start + c] == mv);
+            int hit = (c < n) && (D.eAct[sp.at(start + min(c, n - 1))] == mv);
             unsigned long long bal = __ballot(hit);
             if (bal) { found = start + c0 + __ffsll((long long)bal) - 1; break; }
         }
@@ -575,16 +584,19 @@ __global__ __launch_bounds__(64) void k_reroot(Dev D)
             D.rootN[t] = 0; rootW[t] = (R)0.0; rootP[t] = (R)1.0;
             D.rootBlock[t] = -1; D.nBlocks[t] = 0; D.nEdges[t] = 0;
         }
+        tree_release(D, t, 0);
         return;
     }
-    const int r = D.eChild[tb + found];
-    const int nN = D.eN[tb + found];
-    const R nW = eW[tb + found], nP = eP[tb + found];
+    const size_t ef = edge_at(D, t, found);
+    const int r = D.eChild[ef];
+    const int nN = D.eN[ef];
+    const R nW = eW[ef], nP = eP[ef];
     const int nb = D.nBlocks[t];
     WSYNC();
     if (lane == 0) { D.rootN[t] = nN; rootW[t] = nW; rootP[t] = nP; }
     if (r < 0) {
         if (lane == 0) { D.rootBlock[t] = -1; D.nBlocks[t] = 0; D.nEdges[t] = 0; }
+        tree_release(D, t, 0);
         return;
     }
     // 1. liveness: a block lives iff it is r or its parent block lives (parent index < own index)
@@ -641,18 +653,19 @@ __global__ __launch_bounds__(64) void k_reroot(Dev D)
         int ns = os - sh;
         int nowner = -1, npar = -1;
         if (b != r) { nowner = owner - D.bShift[bb + par]; npar = D.bMap[bb + par]; }
+        const Span so = span_of(D, t, os), sn = span_of(D, t, ns);
         WSYNC();
         for (int c0 = 0; c0 < cnt; c0 += AZ_WAVE) {
             int c = c0 + lane;
             int N = 0, ch = -1; R Wv = 0, P = 0; int16_t a = 0;
             if (c < cnt) {
-                size_t e = tb + os + c;
+                size_t e = so.at(os + c);
                 N = D.eN[e]; Wv = eW[e]; P = eP[e]; ch = D.eChild[e]; a = D.eAct[e];
                 if (ch >= 0) ch = D.bMap[bb + ch];
             }
             WSYNC();
             if (c < cnt) {
-                size_t e = tb + ns + c;
+                size_t e = sn.at(ns + c);
                 D.eN[e] = N; eW[e] = Wv; eP[e] = P; D.eChild[e] = ch; D.eAct[e] = a;
             }
             WSYNC();
@@ -664,6 +677,7 @@ __global__ __launch_bounds__(64) void k_reroot(Dev D)
         WSYNC();
     }
     if (lane == 0) { D.rootBlock[t] = 0; D.nBlocks[t] = nbNew; D.nEdges[t] = neNew; }
+    tree_release(D, t, (neNew + (1 << D.PS) - 1) >> D.PS);   // the pages behind the kept subtree go back to the pool
 }
 
 // ---------------------------------------------------------------------------
@@ -699,6 +713,8 @@ __global__ __launch_bounds__(64) void k_reset(Dev D, const int32_t *slots, int n
     init_state(D.geo, L, s);
     store_ring(D, g, L);
     store_scalars(D, g, s);
+    tree_release(D, 2 * g, 0);
+    tree_release(D, 2 * g + 1, 0);
     if (lane_id() == 0) {
         D.phase[g] = automode ? PH_NEED_START : PH_IDLE;
         D.side[g] = 0; D.dflag[g] = automode ? (0 <= D.dirichlet_before) : 0; D.pdone[g] = 0; D.issued[g] = 0;

@@ -54,7 +54,7 @@ class Engine:
                  max_depth=0, rng_replay=False, seed=0, record_trajectories=False, num_blocks=0, channels=256,
                  tower_dtype="bf16", device=0, search_f64=False, tree_full_policy=0, leaves_per_round=1,
                  virtual_loss=1.0, enforce_superko=False, c_punt=5.0, tower_graphs=None, conv_duo=None,
-                 tower_group_boards=None, match_parallel_towers=None):
+                 tower_group_boards=None, match_parallel_towers=None, tree_pool_edges=0, tree_page_edges=0):
         """The last four arguments are measurement switches (A/B timing, tests).  Left at None they follow the
         environment variables the tools/ scripts set: AZ_NO_GRAPHS, AZ_CONV_DUO=0, AZ_TOWER_GROUP_BOARDS=N,
         AZ_MATCH_PARALLEL_TOWERS; the library itself reads no environment."""
@@ -78,7 +78,8 @@ class Engine:
             device=device, leaves_per_round=int(leaves_per_round), virtual_loss=float(virtual_loss),
             tree_full_policy=int(tree_full_policy), search_f64=int(bool(search_f64)), enforce_superko=int(bool(enforce_superko)),
             c_punt=float(c_punt), tower_no_graphs=int(not tower_graphs), tower_no_duo=int(not conv_duo),
-            tower_group_boards=int(tower_group_boards), match_parallel_towers=int(bool(match_parallel_towers)))
+            tower_group_boards=int(tower_group_boards), match_parallel_towers=int(bool(match_parallel_towers)),
+            tree_pool_edges=int(tree_pool_edges), tree_page_edges=int(tree_page_edges))
         self.cfg = cfg
         # dtype of W / P / priors / values: float64 reproduces a search fed by a float64 evaluator (dummy_eval.py:26-28)
         self.real = np.float64 if search_f64 else np.float32
@@ -216,7 +217,7 @@ class Engine:
         self._ck(self._L.az_search_advance(self._h, s.ctypes.data, s.size, m.ctypes.data))
 
     def grow_trees(self, edge_cap=0, block_cap=0):
-        """Enlarge every tree's arena (0 = double); contents are kept."""
+        """Raise every tree's limits (0 = double) and the shared edge pool with them; contents are kept."""
         self._ck(self._L.az_search_grow_trees(self._h, int(edge_cap), int(block_cap)))
 
     def set_c_punt(self, c_punt):

@@ -209,6 +209,10 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp32"],
                     help="storage type of the tower's weights and activations: bf16 (the headline), f16 (IEEE half: same matrix-core "
                          "rate, 8 times finer rounding), fp32 (vector-ALU parity tower)")
+    ap.add_argument("--tree-pool", type=float, default=1.0 / 3.0,
+                    help="edges in the pool the search trees share, as a fraction of games x 2 trees x the per-tree limit of "
+                         "3 * (sims + 1) * actions (the fullest tree of a search from the opening reaches a third of its limit, "
+                         "and only one of a game's two trees is being searched)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-telemetry", action="store_true", help="no rocm-smi sampling during the timed region (always off under a profiler)")
     ap.add_argument("--no-exchange", action="store_true", help="skip the weight-update / trajectory-gather exercise after the timed region")
@@ -321,7 +325,9 @@ def tower_parity(torch, np, eng, H, O, blocks, channels, planes, device):
     B = min(96, planes.shape[0])
     x = np.ascontiguousarray(planes[:B])
     net = random_net(H, H, O, blocks, channels, seed=0)
-    calibrate_bn(net, torch.from_numpy(x[:4].astype(np.float32)))
+    # statistics from random boards of mixed occupancy (what tools/bf16_search_effect.py and the depth tests use); this run's
+    # leaf boards are all a few plies from the empty board and next to identical, which makes degenerate statistics
+    calibrate_bn(net, torch.from_numpy((np.random.RandomState(7).rand(6, 17, H, H) < 0.3).astype(np.float32)))
     blob = fold_to_blob(net)
     res = {}
     for dt in ("bf16", "f16", "fp32"):
@@ -379,9 +385,9 @@ def main(args):
     H = args.board
     O = H * H + (0 if args.game == "mnk" else 1)
     if args.games <= 0:
-        # two tree arenas per game: 3*(sims+1)*O edges of 18 B and 8*(sims+1) blocks of 24 B each, plus state,
+        # two trees per game: their share of the edge pool (18 B per edge) and 8*(sims+1) blocks of 24 B each, plus state,
         # trajectories and activations (about 0.7 MB); larger batches keep the tower's tiles flowing (fewer tails)
-        per_game = 2 * (3 * (args.sims + 1) * O * 18 + 8 * (args.sims + 1) * 24) + (402 * O * 4 + 402 * 2) + 3 * 441 * 256 * 2 + 64 * 1024
+        per_game = 2 * (int(args.tree_pool * 3 * (args.sims + 1) * O) * 18 + 8 * (args.sims + 1) * 24) + (402 * O * 4 + 402 * 2) + 3 * 441 * 256 * 2 + 64 * 1024
         free, _ = torch.cuda.mem_get_info(local_rank)
         gmax = int(max(256, min(4096, int(0.85 * free) // per_game)))
         # the tower's conv tiles are 256 board points; pick the largest game count whose tiles fill a whole number of
@@ -390,7 +396,8 @@ def main(args):
         args.games = slots_for_whole_tile_rounds(gmax, H, H, cus)
     eng = Engine(args.game, H, H, args.k, n_slots=args.games, max_playout=args.sims, transform_types=8, dirichlet_before=30,
                  max_turn=400, d_alpha=0.03, d_epsilon=0.25, seed=1000 + rank, record_trajectories=True,
-                 num_blocks=args.blocks, channels=args.channels, tower_dtype=args.dtype, device=local_rank)
+                 num_blocks=args.blocks, channels=args.channels, tower_dtype=args.dtype, device=local_rank,
+                 tree_pool_edges=max(1, int(args.tree_pool * 2 * args.games * 3 * (args.sims + 1) * O)))
     # weights: rank 0 builds them, every rank receives them over RCCL and loads them from GPU memory (model update path)
     blob_t = None
     if rank == 0:
@@ -450,8 +457,10 @@ def main(args):
     parity = None
     if rank == 0 and args.dtype != "fp32" and not args.no_tower_parity:
         try:
+            eng.selfplay_select()   # a fresh round's leaves (the finish step of the last timed round consumed its own)
             planes, valid = eng.leaf_batch()
-            parity = tower_parity(torch, np, eng, H, O, args.blocks, args.channels, planes[np.flatnonzero(valid)], local_rank)
+            rows = np.flatnonzero(valid)
+            parity = tower_parity(torch, np, eng, H, O, args.blocks, args.channels, planes[rows if rows.size else slice(None)], local_rank)
         except Exception as e:  # noqa: BLE001
             parity = {"error": "%s: %s" % (type(e).__name__, e)}
 
@@ -485,13 +494,18 @@ def main(args):
             "moves_completed_in_timed_region": total_moves, "completed_moves_per_sec": total_moves / dt,
             "phase_ms_per_round": {"select": c["select_ms"] / rounds, "tower": c["tower_ms"] / rounds,
                                    "finish_move_reroot": c["finish_ms"] / rounds},
-            # tree_full_policy 0 here: an arena overflow would have stopped the run with an error, so 0 skipped
-            # expansions is by construction; the peak shows how far the fullest tree of rank 0 got
+            # tree_full_policy 0 here: a full tree or an empty edge pool would have stopped the run with an error, so 0
+            # skipped expansions is by construction; the peaks show how far the fullest tree and the pool of rank 0 got
             "expansions_skipped": total_skipped,
             "tree_arena_peak": {"edges": c["peak_tree_edges"], "edge_cap": c["tree_edge_cap"],
                                 "blocks": c["peak_tree_blocks"], "block_cap": c["tree_block_cap"],
                                 "frac": max(c["peak_tree_edges"] / max(c["tree_edge_cap"], 1),
                                             c["peak_tree_blocks"] / max(c["tree_block_cap"], 1))},
+            "tree_edge_pool": {"page_edges": c["tree_page_edges"], "pages": c["tree_pool_pages"], "pages_peak": c["tree_pool_pages_peak"],
+                               "pages_in_use_at_end": c["tree_pool_pages_in_use"],
+                               "bytes": c["tree_pool_pages"] * c["tree_page_edges"] * 18,
+                               "bytes_if_every_tree_had_its_own_arena": 2 * args.games * c["tree_edge_cap"] * 18,
+                               "frac_of_pool_used_at_peak": c["tree_pool_pages_peak"] / max(c["tree_pool_pages"], 1)},
             "tree_stats_per_sim": {"levels": c["levels"] / max(c["evals"], 1), "children_scanned": c["children_scanned"] / max(c["evals"], 1)},
             "roofline": {
                 "bound": bound, "kernel": eng.tower_conv_kernel(),

@@ -32,7 +32,7 @@ extern "C" {
 #define AZ_ERR_ARG (-1)
 #define AZ_ERR_HIP (-2)
 #define AZ_ERR_ILLEGAL_MOVE (-3)   /* the module-level IllegalMove of the env modules */
-#define AZ_ERR_TREE_FULL (-4)      /* a tree arena overflowed (raise tree_*_cap) */
+#define AZ_ERR_TREE_FULL (-4)      /* a tree reached tree_edge_cap / tree_block_cap, or the shared edge pool ran out of pages */
 #define AZ_ERR_RNG_UNDERFLOW (-5)  /* a replay stream ran dry */
 #define AZ_ERR_DEPTH (-6)          /* a playout went deeper than max_depth */
 #define AZ_ERR_STATE (-7)          /* call not valid in the handle's current phase */
@@ -61,7 +61,8 @@ typedef struct az_config {
     int32_t dirichlet_before;  /* noise while turns <= this */
     int32_t max_turn;          /* game stops when turns > this */
     double d_alpha, d_epsilon;
-    int32_t tree_edge_cap;     /* edges per tree; 0 = 3*(max_playout+1)*O */
+    int32_t tree_edge_cap;     /* most edges one tree may hold; 0 = 3*(max_playout+1)*O.  The edges themselves come in pages from
+                                  one pool that all trees of the engine share (tree_pool_edges below) */
     int32_t tree_block_cap;    /* expanded nodes per tree; 0 = 8*(max_playout+1) */
     int32_t max_depth;         /* playout path bound; 0 = 1024 */
     int32_t rng_replay;        /* 1: draws come from az_rng_inject streams; 0: device generator */
@@ -102,6 +103,17 @@ typedef struct az_config {
                                   queue of its own; +60 % match throughput when neither share fills the chip).  Off by default:
                                   with many streams created earlier in the process, rounds of two concurrently running towers
                                   have been seen to stop making progress on this runtime */
+    /* The pool of tree edges.  The reference's tree is a heap of Python objects without a limit (search/mcts.py:30-52); here
+     * a tree numbers its edges 0 .. n-1 and a page table maps each page of that range to a page of one pool per engine, so
+     * memory follows what the trees hold at the moment, not n_trees times the largest tree. */
+    int64_t tree_pool_edges;   /* edges in the pool; 0 = automatic: n_trees * tree_edge_cap (every tree can reach its cap at once)
+                                  when tree_edge_cap is given, half of that when tree_edge_cap is 0 as well - the default cap is
+                                  generous: the fullest tree of whole 400-ply Go 19x19 games reached 33-56 % of it.  A pool that
+                                  runs out is handled like a full tree (tree_full_policy).  Never fewer than one page per tree:
+                                  a tree's first page is its own, so a root's children always have a place */
+    int32_t tree_page_edges;   /* edges per page, a power of two not below the number of actions; 0 = 4 * (actions rounded up
+                                  to a power of two), at least 64 */
+    int32_t reserved0;         /* 0 */
 } az_config;
 
 /* Fixed-layout copy of one game state (attributes of env/*.py GameState). */
@@ -135,6 +147,10 @@ typedef struct az_counters {
     uint64_t peak_tree_blocks;
     uint64_t tree_edge_cap;       /* ... against the arena sizes in force (az_config.tree_edge_cap / tree_block_cap) */
     uint64_t tree_block_cap;
+    uint64_t tree_page_edges;     /* the shared pool of tree edges: edges per page, */
+    uint64_t tree_pool_pages;     /* pages in the pool, */
+    uint64_t tree_pool_pages_in_use;  /* pages the trees hold now (never fewer than one each), */
+    uint64_t tree_pool_pages_peak;    /* and the most they have held at once since the last reset */
 } az_counters;
 
 /* ---- lifetime ------------------------------------------------------- */
@@ -204,8 +220,9 @@ int az_search_choose(az_engine *h, int32_t slot, int32_t side, double u, int32_t
 /* MCTSearch.update_with_move for one tree / Player.ack for both trees of a slot */
 int az_search_advance_tree(az_engine *h, int32_t slot, int32_t side, int32_t move);
 int az_search_advance(az_engine *h, const int32_t *slots, int32_t n, const int32_t *moves);
-/* Enlarge the arenas of every tree to edge_cap edges / block_cap expanded nodes (0 = twice the present size; never
- * shrinks); the trees keep their contents.  What tree_full_policy 2 does by itself. */
+/* Raise the limits of every tree to edge_cap edges / block_cap expanded nodes (0 = twice the present value; never
+ * shrinks) and enlarge the shared edge pool by the same factor as edge_cap; the trees keep their contents.  What
+ * tree_full_policy 2 does by itself. */
 int az_search_grow_trees(az_engine *h, int32_t edge_cap, int32_t block_cap);
 /* nodes (edges) and expanded nodes currently held by a tree */
 int az_search_tree_size(az_engine *h, int32_t slot, int32_t side, int32_t *edges, int32_t *blocks);

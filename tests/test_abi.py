@@ -34,7 +34,7 @@ def test_binding_covers_header():
 def test_struct_sizes_match_header():
     # az_state_blob: 8 boards of 384 bytes + 14 int32
     assert ctypes.sizeof(_lib.AzStateBlob) == 8 * 384 + 14 * 4
-    assert ctypes.sizeof(_lib.AzCounters) == 21 * 8
+    assert ctypes.sizeof(_lib.AzCounters) == 25 * 8
 
 
 def header_struct_fields(name):
