@@ -1,12 +1,11 @@
 #!/bin/bash
-# A/B of the tower's board-group size in the self-play bench, same box, back to back: arguments boards[:streams]
-# (AZ_TOWER_GROUP_BOARDS: -1 = whole batch per layer, 0 = automatic; AZ_TOWER_GROUP_STREAMS 1 or 2).
+# A/B of the tower's board-group size in the self-play bench, same box, back to back: one argument per run, the boards per
+# group (AZ_TOWER_GROUP_BOARDS: -1 = whole batch per layer, 0 = automatic, N = groups of N boards).
 out=gpurun_out/group_sweep.log
 : > $out
-for spec in "$@"; do
-  g=${spec%%:*}; ns=${spec##*:}; [ "$ns" = "$spec" ] && ns=2
-  echo "== AZ_TOWER_GROUP_BOARDS=$g AZ_TOWER_GROUP_STREAMS=$ns" >> $out
-  AZ_TOWER_GROUP_STREAMS=$ns AZ_TOWER_GROUP_BOARDS=$g timeout -k 10 200 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+for g in "$@"; do
+  echo "== AZ_TOWER_GROUP_BOARDS=$g" >> $out
+  AZ_TOWER_GROUP_BOARDS=$g timeout -k 10 200 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 for ln in sys.stdin:
     if ln.startswith('{'):
