@@ -106,7 +106,8 @@ struct Dev {
     int32_t *pt;               // [2G][PTC] pool page of each page of a tree (entries below nPages are valid)
     int32_t *nPages;           // [2G] pages a tree holds: max(1, ceil(nEdges / page)); page 0 of tree t is pool page t for good
     int32_t *pool_free;        // [pool_pages] stack of free pool pages
-    int32_t *pool_top;         // [0] free pages on the stack; [1] the lowest [0] has been since the counters were reset
+    int32_t *pool_top;         // [0] free pages on the stack; [1] the lowest [0] was when pages were last given back (with
+                               // the present [0], the low-water mark since the counters were reset)
     int32_t *bStart, *bCount, *bOwner, *bParent, *bMap, *bShift;             // [2G][BC]
     int32_t *pending;    // [2G] move to re-root with, NOMOVE = none
     // rng
@@ -194,7 +195,6 @@ __device__ __forceinline__ int tree_reserve(const Dev &D, int t, int n_edges)
             int32_t *pt = D.pt + (size_t)t * D.PTC;
             for (int i = 0; i < k; i++) pt[have + i] = D.pool_free[top - k + i];
             D.nPages[t] = need;
-            if (top - k < D.pool_top[1]) atomicMin(&D.pool_top[1], top - k);
         }
     }
     ok = __shfl(ok, 0, 64);
@@ -213,7 +213,12 @@ __device__ __forceinline__ void tree_release(const Dev &D, int t, int keep)
     if (have <= keep) return;
     const int k = have - keep;
     int base = 0;
-    if (lane_id() == 0) base = atomicAdd(&D.pool_top[0], k);
+    if (lane_id() == 0) {
+        base = atomicAdd(&D.pool_top[0], k);
+        // the free count only falls while pages are being taken and only rises here: its low-water mark is what the first
+        // release after a stretch of taking sees
+        if (base < D.pool_top[1]) atomicMin(&D.pool_top[1], base);
+    }
     base = __shfl(base, 0, 64);
     const int32_t *pt = D.pt + (size_t)t * D.PTC;
     for (int i = lane_id(); i < k; i += AZ_WAVE) D.pool_free[base + i] = pt[keep + i];

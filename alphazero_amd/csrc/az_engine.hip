@@ -1522,7 +1522,7 @@ extern "C" int az_counters_get(az_engine *h, az_counters *out)
         int32_t top[2];
         HIPCHK(hipMemcpy(top, h->D.pool_top, sizeof top, hipMemcpyDeviceToHost));
         out->tree_page_edges = 1ull << h->D.PS; out->tree_pool_pages = h->D.pool_pages;
-        out->tree_pool_pages_in_use = h->D.pool_pages - top[0]; out->tree_pool_pages_peak = h->D.pool_pages - top[1];
+        out->tree_pool_pages_in_use = h->D.pool_pages - top[0]; out->tree_pool_pages_peak = h->D.pool_pages - std::min(top[0], top[1]);
     }
     out->conv_ms = 0; out->conv_launches = 0; out->conv_flops_per_launch = 0;
     if (h->tower) {

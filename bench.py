@@ -38,11 +38,15 @@ VALU_PEAK_TFLOPS_FP32 = 157.3   # float32 vector peak (the fp32 parity tower run
 def measured_traffic(games, board, channels):
     """HBM bytes per launch of the dominant conv kernel from the committed PMC passes (they cannot be
     collected inside a timed run); None when the workload is not the one the counters were taken on."""
-    path = os.path.join(ROOT, "profiles", "round2_traffic.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-    except OSError:
+    d = None
+    for name in ("round3_traffic.json", "round2_traffic.json"):   # the newest committed counter passes
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            break
+        except (OSError, ValueError):
+            continue
+    if d is None:
         return None, None
     if (d.get("board"), d.get("channels")) != (board, channels):
         return None, None
@@ -446,6 +450,12 @@ def main(args):
     whole_searches = total_moves >= total_games
     moves_per_s = total_moves / dt if whole_searches else steady_moves_per_s
 
+    # the evaluator outputs the last timed round's finish step used: finite, priors a distribution (a 16-bit tower whose
+    # activations overflowed would show here as inf / nan)
+    lp, lv = eng.leaf_outputs()
+    outputs_ok = bool(np.isfinite(lp).all() and np.isfinite(lv).all() and np.abs(lp.sum(axis=1) - 1.0).max() < 1e-3 and np.abs(lv).max() <= 1.0)
+    del lp, lv
+
     # ---- after the timed region: the exchanges of a multi-GPU job, and the tower's bf16 error on this run's boards
     exchange = None
     if not args.no_exchange:
@@ -496,6 +506,7 @@ def main(args):
                                    "finish_move_reroot": c["finish_ms"] / rounds},
             # tree_full_policy 0 here: a full tree or an empty edge pool would have stopped the run with an error, so 0
             # skipped expansions is by construction; the peaks show how far the fullest tree and the pool of rank 0 got
+            "leaf_outputs_finite_and_normalised": outputs_ok,
             "expansions_skipped": total_skipped,
             "tree_arena_peak": {"edges": c["peak_tree_edges"], "edge_cap": c["tree_edge_cap"],
                                 "blocks": c["peak_tree_blocks"], "block_cap": c["tree_block_cap"],

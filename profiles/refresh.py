@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Rewrites the committed summaries from the raw outputs of profiles/collect.sh <tag> and profiles/collect_mfma.sh <tag2>
 (gpurun_out/prof_<tag>, gpurun_out/prof_<tag2>).
-    python profiles/refresh.py final mfma_final [tag of profiles/collect_pmc_short.sh]"""
+    python profiles/refresh.py final mfma_final [tag of profiles/collect_pmc_short.sh]
+AZ_PROFILE_ROUND names the files written (default round3: profiles/round3_kernel_stats.txt, ...)."""
 import csv
 import json
 import os
@@ -28,8 +29,8 @@ def val(txt, pat):
 
 
 # kernel trace
-ROUND = "round2"
-hdr = ("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline   (MI355X, 3993 games per GPU, "
+ROUND = os.environ.get("AZ_PROFILE_ROUND", "round3")
+hdr = ("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-tower-parity --no-exchange   (MI355X, 3993 games per GPU, "
        "41 rounds per step; the 3x3 256->256 convolutions run the two-workgroups-per-CU kernel k_conv3x3_c256_bf16_duo, one launch per layer and "
        "group of 363 boards; collected by "
        "profiles/collect.sh)\n")
@@ -49,7 +50,7 @@ w = run(os.path.join(HERE, "pmc_summary.py"), os.path.join(PC, "pmc_write", "wri
 fp, fr, ws = val(f, "duo<false"), val(f, "duo<true"), val(w, "duo<true")
 rd, wr = 2 * (fp + fr) / 2 * 1024 / 1e6, ws * 1024 / 1e6
 a_in, a_out = boards * 441 * 512 / 1e6, boards * 361 * 512 / 1e6
-hdr2 = ("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 0 --rounds-per-step 2 --no-cpu-baseline   "
+hdr2 = ("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 0 --rounds-per-step 2 --no-cpu-baseline --no-tower-parity --no-exchange   "
         "(profiles/collect_pmc_short.sh: the counter passes abort inside the profiler on longer runs of this many dispatches; "
         "3993 games per GPU, the tower in groups of %.0f boards)\n# counter unit: KiB per dispatch (mean).  On gfx950 FETCH_SIZE counts 128-B "
         "read requests as 64 B: double it for bytes.\n# The counters sit between L2 and the fabric: they count what leaves the XCDs' L2s, "

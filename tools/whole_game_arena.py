@@ -50,3 +50,6 @@ print("  evaluations %d, expansions skipped %d (%.2e of evaluations)" % (c["eval
 print("  fullest tree: %d of %d edges (%.1f %%), %d of %d blocks (%.1f %%)" % (
     c["peak_tree_edges"], c["tree_edge_cap"], 100.0 * c["peak_tree_edges"] / c["tree_edge_cap"],
     c["peak_tree_blocks"], c["tree_block_cap"], 100.0 * c["peak_tree_blocks"] / c["tree_block_cap"]))
+print("  shared edge pool: at most %d of %d pages of %d edges in use at once (%.1f %%; %.1f %% of what one arena per tree would take)" % (
+    c["tree_pool_pages_peak"], c["tree_pool_pages"], c["tree_page_edges"], 100.0 * c["tree_pool_pages_peak"] / c["tree_pool_pages"],
+    100.0 * c["tree_pool_pages_peak"] * c["tree_page_edges"] / (2.0 * par * c["tree_edge_cap"])))
