@@ -221,6 +221,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-telemetry", action="store_true", help="no rocm-smi sampling during the timed region (always off under a profiler)")
     ap.add_argument("--no-exchange", action="store_true", help="skip the weight-update / trajectory-gather exercise after the timed region")
     ap.add_argument("--no-tower-parity", action="store_true", help="skip the bf16-against-fp32 tower comparison after the timed region")
+    ap.add_argument("--post-timeout", type=float, default=300.0,
+                    help="seconds the work after the timed region (exchanges, parity check, CPU baseline) may take before the "
+                         "measured line is printed without it and the ranks leave")
     ap.add_argument("--exchange-games", type=int, default=1024, help="synthetic finished games (400 plies each) every rank packs and sends")
     return ap.parse_args(argv)
 
@@ -456,24 +459,8 @@ def main(args):
     outputs_ok = bool(np.isfinite(lp).all() and np.isfinite(lv).all() and np.abs(lp.sum(axis=1) - 1.0).max() < 1e-3 and np.abs(lv).max() <= 1.0)
     del lp, lv
 
-    # ---- after the timed region: the exchanges of a multi-GPU job, and the tower's bf16 error on this run's boards
-    exchange = None
-    if not args.no_exchange:
-        try:
-            exchange = exchange_exercise(eng, parallel, torch, dist, rank, world, dev, blob_t, O,
-                                         max(1, min(args.exchange_games, args.games)), backend)
-        except Exception as e:  # noqa: BLE001 - the measured line must survive a failed exercise, and say so
-            exchange = {"error": "%s: %s" % (type(e).__name__, e)}
-    parity = None
-    if rank == 0 and args.dtype != "fp32" and not args.no_tower_parity:
-        try:
-            eng.selfplay_select()   # a fresh round's leaves (the finish step of the last timed round consumed its own)
-            planes, valid = eng.leaf_batch()
-            rows = np.flatnonzero(valid)
-            parity = tower_parity(torch, np, eng, H, O, args.blocks, args.channels, planes[rows if rows.size else slice(None)], local_rank)
-        except Exception as e:  # noqa: BLE001
-            parity = {"error": "%s: %s" % (type(e).__name__, e)}
-
+    # ---- the measured line is complete here (rank 0); what follows only adds to it
+    out = None
     if rank == 0:
         conv_ms = c["conv_ms"] / max(c["conv_launches"], 1)
         achieved = c["conv_flops_per_launch"] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
@@ -531,16 +518,62 @@ def main(args):
             "hbm_kernels": hbm_kernels(c, H * H, O, rounds),
             "gpu_telemetry": gpu_telemetry,
             "tower_tflops_end_to_end": (c["tower_evals"] * eng.tower_flops_per_eval()) / (c["tower_ms"] * 1e-3) / 1e12 if c["tower_ms"] > 0 else 0.0,
-            "exchange": exchange,
-            "tower_parity": parity,
+            "exchange": None, "tower_parity": None,
         }
-        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only; at N>1 the other ranks would idle behind it
-            out["cpu_baseline"] = cpu_baseline(args.game, H, args.k, args.blocks, args.channels, args.sims)
-        _emit(json.dumps(out))
+
+    # ---- after the timed region: the exchanges of a multi-GPU job, the tower's 16-bit error on this run's boards, the CPU
+    # baseline.  None of it may cost the measurement: if it has not finished after --post-timeout seconds (a collective that
+    # never completes on some fabric), rank 0 prints the line as it stands, saying so, and every rank leaves.
+    import threading
+    lock = threading.Lock()
+    state = {"emitted": False}
+
+    def emit_once(note=None):
+        with lock:
+            if state["emitted"]:
+                return
+            state["emitted"] = True
+            if rank == 0:
+                if note:
+                    out["post_region_note"] = note
+                _emit(json.dumps(out))
+
+    def expired():
+        emit_once("the work after the timed region did not finish within %.0f s and was abandoned" % args.post_timeout)
+        os._exit(0)
+
+    timer = threading.Timer(args.post_timeout, expired)
+    timer.daemon = True
+    timer.start()
+
+    def record(key, fn):
+        try:
+            val = fn()
+        except Exception as e:  # noqa: BLE001 - a failed exercise is reported in its place
+            val = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0:
+            with lock:
+                if not state["emitted"]:
+                    out[key] = val
+
+    if not args.no_exchange:
+        record("exchange", lambda: exchange_exercise(eng, parallel, torch, dist, rank, world, dev, blob_t, O,
+                                                     max(1, min(args.exchange_games, args.games)), backend))
+    if rank == 0 and args.dtype != "fp32" and not args.no_tower_parity:
+        def parity():
+            eng.selfplay_select()   # a fresh round's leaves (the finish step of the last timed round consumed its own)
+            planes, valid = eng.leaf_batch()
+            rows = np.flatnonzero(valid)
+            return tower_parity(torch, np, eng, H, O, args.blocks, args.channels, planes[rows if rows.size else slice(None)], local_rank)
+        record("tower_parity", parity)
+    if rank == 0 and not args.no_cpu_baseline and world == 1:  # reported at N=1 only; at N>1 the other ranks would idle behind it
+        record("cpu_baseline", lambda: cpu_baseline(args.game, H, args.k, args.blocks, args.channels, args.sims))
+    emit_once()
     eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    timer.cancel()
 
 
 # The one JSON line must be the only thing on stdout, but libraries write there too (RCCL prints a version banner when

@@ -36,3 +36,11 @@ print("%s %dx%d, %d sims, %d blocks, %d parallel: %d games (%d plies) in %.1f s"
 print("  engine: %d moves, %.1f s of GPU phases -> %.0f moves/s; end to end incl. host: %.0f moves/s (all %d moves / wall)"
       % (c["moves"], gpu_s, c["moves"] / gpu_s, c["moves"] / dt, c["moves"]))
 print("  history bytes returned: %.1f MB" % (sum(h[0].nbytes + h[1].nbytes + h[2].nbytes for h in hist) / 1e6))
+# the shared pool of tree edges after thousands of games started and ended in these slots: every page in use must belong to
+# exactly one tree (a page lost at a restart or a re-root would show here as pages in use that no tree holds)
+page = c["tree_page_edges"]
+held = sum(max(1, -(-sp.eng.tree_size(s, side)[0] // page)) for s in range(par) for side in (0, 1))
+print("  tree edge pool: %d pages of %d edges, peak %d (%.1f %%), in use now %d, held by the trees %d -> %s; expansions skipped %d"
+      % (c["tree_pool_pages"], page, c["tree_pool_pages_peak"], 100.0 * c["tree_pool_pages_peak"] / c["tree_pool_pages"],
+         c["tree_pool_pages_in_use"], held, "no page lost" if held == c["tree_pool_pages_in_use"] else "PAGES LOST", c["expansions_skipped"]))
+assert held == c["tree_pool_pages_in_use"]
