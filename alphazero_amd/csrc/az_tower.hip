@@ -625,15 +625,23 @@ static int forward_t(Tower *t, const int8_t *planes, int B, float *priors, float
 const char *tower_conv_kernel_name(const Tower *t, int B, bool device_count)
 {
     if (!is16(t->dtype)) return "k_conv3x3_f32 (vector ALU, float32 operands, float64 accumulation)";
+    // the 16-bit kernels are one template; its last parameter is the operand format (0: bf16, 1: IEEE half precision)
+    const bool h = t->dtype == 2;
     const int g = tower_group_boards(t, B);
     const int M = (g ? g : B) * t->HW;
-    if (!device_count && M <= SMALL_BATCH_POINTS && t->C % 64 == 0) return "k_conv3x3_bf16_small (32 points x 32/64 channels per workgroup, reduction axis split over the waves)";
-    if (t->C != 256) return "k_conv3x3_bf16 (per-tap gather, bf16 MFMA 16x16x32)";
+    if (!device_count && M <= SMALL_BATCH_POINTS && t->C % 64 == 0)
+        return h ? "k_conv3x3_bf16_small<..., 1> (32 points x 32/64 channels per workgroup, reduction axis split over the waves, f16 operands)"
+                 : "k_conv3x3_bf16_small (32 points x 32/64 channels per workgroup, reduction axis split over the waves)";
+    if (t->C != 256) return h ? "k_conv3x3_bf16<..., 1> (per-tap gather, f16 MFMA 16x16x32)" : "k_conv3x3_bf16 (per-tap gather, bf16 MFMA 16x16x32)";
     const int span = conv_slab_span(t->HW, t->W, t->PP);
     if (t->use_duo && conv_channel_split(M) == 1 && span <= 27 * 16)
-        return "k_conv3x3_c256_bf16_duo (3x3 256->256 implicit GEMM, bf16 MFMA 16x16x32, two 4-wave workgroups per CU)";
-    if (span <= 4 * 128) return "k_conv3x3_c256_bf16_slab (3x3 256->256 implicit GEMM, bf16 MFMA 16x16x32, one 8-wave workgroup per CU)";
-    return "k_conv3x3_c256_bf16 (per-tap gather of both operands, bf16 MFMA 16x16x32)";
+        return h ? "k_conv3x3_c256_bf16_duo<..., 1> (3x3 256->256 implicit GEMM, f16 MFMA 16x16x32, two 4-wave workgroups per CU)"
+                 : "k_conv3x3_c256_bf16_duo (3x3 256->256 implicit GEMM, bf16 MFMA 16x16x32, two 4-wave workgroups per CU)";
+    if (span <= 4 * 128)
+        return h ? "k_conv3x3_c256_bf16_slab<..., 1> (3x3 256->256 implicit GEMM, f16 MFMA 16x16x32, one 8-wave workgroup per CU)"
+                 : "k_conv3x3_c256_bf16_slab (3x3 256->256 implicit GEMM, bf16 MFMA 16x16x32, one 8-wave workgroup per CU)";
+    return h ? "k_conv3x3_c256_bf16<..., 1> (per-tap gather of both operands, f16 MFMA 16x16x32)"
+             : "k_conv3x3_c256_bf16 (per-tap gather of both operands, bf16 MFMA 16x16x32)";
 }
 
 static int forward_any(Tower *t, const int8_t *planes, int B, float *priors, float *values, hipStream_t st, const int32_t *rows,

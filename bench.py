@@ -221,6 +221,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-telemetry", action="store_true", help="no rocm-smi sampling during the timed region (always off under a profiler)")
     ap.add_argument("--no-exchange", action="store_true", help="skip the weight-update / trajectory-gather exercise after the timed region")
     ap.add_argument("--no-tower-parity", action="store_true", help="skip the bf16-against-fp32 tower comparison after the timed region")
+    ap.add_argument("--no-other-format", action="store_true", help="skip the short run with the other 16-bit tower format after the timed region")
     ap.add_argument("--post-timeout", type=float, default=300.0,
                     help="seconds the work after the timed region (exchanges, parity check, CPU baseline) may take before the "
                          "measured line is printed without it and the ranks leave")
@@ -320,6 +321,34 @@ def exchange_exercise(eng, parallel, torch, dist, rank, world, dev, blob_t, O, n
                            "bytes_into_rank0": recv, "gather_gb_per_s": (recv / (t_gather * 1e-3) / 1e9) if t_gather > 0 and recv else None,
                            "received_ok": bool(ok), "wire": "uint8 view of the packed int16 tensor, point to point, 64 MiB chunks"}
     return out
+
+
+def other_16bit_format(args, Engine, fold_to_blob, random_net, H, O, device, rps):
+    """The same workload for a few steps with the other 16-bit format of the tower (half precision when the run is bf16 and the
+    other way round): the bf16 tower is the faster one, the f16 tower the one whose value output stays within 1e-2 of
+    float32 at 20 blocks (`tower_parity`), and this says on the same card, minutes apart, what that costs."""
+    other = "f16" if args.dtype == "bf16" else "bf16"
+    eng = Engine(args.game, H, H, args.k, n_slots=args.games, max_playout=args.sims, transform_types=8, dirichlet_before=30,
+                 max_turn=400, d_alpha=0.03, d_epsilon=0.25, seed=1000, num_blocks=args.blocks, channels=args.channels,
+                 tower_dtype=other, device=device, tree_pool_edges=max(1, int(args.tree_pool * 2 * args.games * 3 * (args.sims + 1) * O)))
+    try:
+        eng.tower_load(fold_to_blob(random_net(H, H, O, args.blocks, args.channels, seed=0)))
+        eng.selfplay_start()
+        eng.tower_profile(8)
+        eng.selfplay_run(rps)
+        eng.counters_reset()
+        steps = 3
+        t0 = time.perf_counter()
+        eng.selfplay_run(steps * rps)
+        eng.sync()
+        dt = time.perf_counter() - t0
+        c = eng.counters()
+        conv_ms = c["conv_ms"] / max(c["conv_launches"], 1)
+        return {"dtype": other, "steps": steps, "rounds": steps * rps, "sims_per_sec": c["evals"] / dt, "ms_per_round": dt * 1e3 / (steps * rps),
+                "steady_state_moves_per_sec": c["evals"] / dt / (args.sims + 1),
+                "conv_tflops": c["conv_flops_per_launch"] / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0, "kernel": eng.tower_conv_kernel()}
+    finally:
+        eng.close()
 
 
 def tower_parity(torch, np, eng, H, O, blocks, channels, planes, device):
@@ -518,7 +547,7 @@ def main(args):
             "hbm_kernels": hbm_kernels(c, H * H, O, rounds),
             "gpu_telemetry": gpu_telemetry,
             "tower_tflops_end_to_end": (c["tower_evals"] * eng.tower_flops_per_eval()) / (c["tower_ms"] * 1e-3) / 1e12 if c["tower_ms"] > 0 else 0.0,
-            "exchange": None, "tower_parity": None,
+            "exchange": None, "tower_parity": None, "other_16bit_format": None,
         }
 
     # ---- after the timed region: the exchanges of a multi-GPU job, the tower's 16-bit error on this run's boards, the CPU
@@ -566,6 +595,8 @@ def main(args):
             rows = np.flatnonzero(valid)
             return tower_parity(torch, np, eng, H, O, args.blocks, args.channels, planes[rows if rows.size else slice(None)], local_rank)
         record("tower_parity", parity)
+    if rank == 0 and world == 1 and args.dtype != "fp32" and not args.no_other_format:   # at N=1 only, like the CPU baseline
+        record("other_16bit_format", lambda: other_16bit_format(args, Engine, fold_to_blob, random_net, H, O, local_rank, rps))
     if rank == 0 and not args.no_cpu_baseline and world == 1:  # reported at N=1 only; at N>1 the other ranks would idle behind it
         record("cpu_baseline", lambda: cpu_baseline(args.game, H, args.k, args.blocks, args.channels, args.sims))
     emit_once()

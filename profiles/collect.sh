@@ -8,7 +8,7 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
-ARGS="$REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-tower-parity --no-exchange"
+ARGS="$REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-tower-parity --no-exchange --no-other-format"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python3 $ARGS > $OUT/trace_bench.json 2> $OUT/trace.err
 [ "$PMC" = 1 ] || { ls -R $OUT | head -20; exit 0; }
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 $ARGS > $OUT/fetch_bench.json 2> $OUT/fetch.err

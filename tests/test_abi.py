@@ -65,7 +65,7 @@ def test_binding_structs_follow_the_header_member_by_member():
 
 
 def test_integration_guide_stub_matches_the_binding():
-    """The ctypes stub printed in INTEGRATION.md is what a maintainer would copy: same members, same order."""
+    """The ctypes stub printed in the integration guide is what a maintainer would copy: same members, same order."""
     txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     stub = txt[txt.index("class AzConfig(C.Structure)"):txt.index("L.az_engine_create.restype")]
     assert re.findall(r'\("([a-z0-9_]+)", C\.c_', stub) == [f[0] for f in _lib.AzConfig._fields_]

@@ -5,7 +5,7 @@ out=gpurun_out/duo_ab_boards.log
 run() {
   for d in 0 1 0 1; do
     echo "== $* AZ_CONV_DUO=$d" >> $out
-    AZ_CONV_DUO=$d timeout -k 10 200 python bench.py --steps 6 --warmup 2 --no-cpu-baseline "$@" 2>/dev/null | python -c "
+    AZ_CONV_DUO=$d timeout -k 10 200 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-other-format --no-tower-parity --no-exchange "$@" 2>/dev/null | python -c "
 import json,sys
 for ln in sys.stdin:
     if ln.startswith('{'):

@@ -5,7 +5,7 @@ out=gpurun_out/f16_ab.log
 : > $out
 for dt in bf16 f16 bf16 f16; do
   echo "== --dtype $dt" >> $out
-  timeout -k 10 200 python3 bench.py --dtype $dt --steps 6 --warmup 2 --no-cpu-baseline --no-tower-parity --no-exchange 2>/dev/null | python3 -c "
+  timeout -k 10 200 python3 bench.py --dtype $dt --steps 6 --warmup 2 --no-cpu-baseline --no-other-format --no-tower-parity --no-exchange 2>/dev/null | python3 -c "
 import json,sys
 for ln in sys.stdin:
     if ln.startswith('{'):

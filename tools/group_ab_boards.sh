@@ -5,7 +5,7 @@ out=gpurun_out/group_ab_boards.log
 run() {
   for g in -1 0 -1 0; do
     echo "== $* AZ_TOWER_GROUP_BOARDS=$g" >> $out
-    AZ_TOWER_GROUP_BOARDS=$g timeout -k 10 200 python bench.py --steps 6 --warmup 2 --no-cpu-baseline "$@" 2>/dev/null | python -c "
+    AZ_TOWER_GROUP_BOARDS=$g timeout -k 10 200 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-other-format --no-tower-parity --no-exchange "$@" 2>/dev/null | python -c "
 import json,sys
 for ln in sys.stdin:
     if ln.startswith('{'):

@@ -5,7 +5,7 @@ out=gpurun_out/group_sweep.log
 : > $out
 for g in "$@"; do
   echo "== AZ_TOWER_GROUP_BOARDS=$g" >> $out
-  AZ_TOWER_GROUP_BOARDS=$g timeout -k 10 200 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+  AZ_TOWER_GROUP_BOARDS=$g timeout -k 10 200 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-other-format 2>/dev/null | python -c "
 import json,sys
 for ln in sys.stdin:
     if ln.startswith('{'):

@@ -6,7 +6,7 @@ out=gpurun_out/power_watch.log
 rocm-smi --showmaxpower 2>&1 | grep -i "power" >> $out
 echo "== metrics before" >> $out
 timeout 20 rocm-smi --showmetrics 2>&1 | grep -iE "power|residency|throttle|gfxclk|current_gfx|average_gfx|temperature_hotspot|energy|activity" >> $out
-timeout -k 10 300 python bench.py --no-cpu-baseline "$@" > gpurun_out/power_bench.log 2>&1 &
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-other-format --no-tower-parity --no-exchange "$@" > gpurun_out/power_bench.log 2>&1 &
 pid=$!
 sleep 12
 for i in 1 2 3; do

@@ -5,7 +5,7 @@ out=gpurun_out/so_ab.log
 for v in old new old new; do
   if [ $v = old ]; then cp tools/prev/libazamd.so alphazero_amd/csrc/libazamd.so; else cp tools/prev/libazamd_new.so alphazero_amd/csrc/libazamd.so; fi
   echo "== $v" >> $out
-  timeout -k 10 200 python bench.py --steps 6 --warmup 2 --no-cpu-baseline "$@" 2>/dev/null | python -c "
+  timeout -k 10 200 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-other-format "$@" 2>/dev/null | python -c "
 import json,sys
 for ln in sys.stdin:
     if ln.startswith('{'):
