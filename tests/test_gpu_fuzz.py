@@ -1,5 +1,6 @@
 """GPU parity on randomly drawn configurations: game, board, simulation count, noise horizon, game length, slot count,
-page size and size of the shared edge pool, tree limits with the growing policy - whole games of the HIP engine against
+page size and size of the shared edge pool, tree limits with the growing policy, leaves per round (the virtual-loss
+schedule, defined by the oracle's oz_tree_search_k), float32 or float64 search statistics - whole games of the HIP engine against
 the C oracle's oz_play_game, visit for visit.  The fixed cases of the other test files pin known shapes; this one walks
 the space between them (children straddling pages, trees emptied and refilled by re-roots, pools that run dry and grow).
 
@@ -49,7 +50,10 @@ def draw(seed):
         kw.update(tree_pool_edges=int(2 * G * max(64, o2) * (1 + r.randint(3))), tree_full_policy=2)
     else:              # undersized per-tree limits, grown on demand
         kw.update(tree_edge_cap=int(O * (1 + r.randint(4))), tree_block_cap=int(2 + r.randint(6)), tree_full_policy=2)
-    return dict(game=game, H=H, k=k, P=P, tt=tt, db=db, mt=mt, G=G, O=O, kw=kw)
+    K = int(r.choice([1, 1, 1, 2, 3, 5, 8]))
+    vloss = float(r.choice([0.25, 1.0]))
+    f64 = bool(r.rand() < 0.2)
+    return dict(game=game, H=H, k=k, P=P, tt=tt, db=db, mt=mt, G=G, O=O, kw=kw, K=K, vloss=vloss, f64=f64)
 
 
 @pytest.mark.parametrize("seed", range(SEED0, SEED0 + N))
@@ -57,9 +61,10 @@ def test_random_configuration_against_the_oracle(seed):
     from alphazero_amd.engine import Engine
     c = draw(seed)
     game, H, k, P, tt, db, mt, G, O = (c[x] for x in ("game", "H", "k", "P", "tt", "db", "mt", "G", "O"))
+    K, vloss, f64 = c["K"], c["vloss"], c["f64"]
     rng = np.random.RandomState(seed)
     eng = Engine(game, H, H, k, n_slots=G, max_playout=P, transform_types=tt, dirichlet_before=db, max_turn=mt, rng_replay=True,
-                 record_trajectories=True, **c["kw"])
+                 record_trajectories=True, leaves_per_round=K, virtual_loss=vloss, search_f64=f64, **c["kw"])
     streams = []
     for s in range(G):
         st = (rng.randint(0, 8, size=(mt + 2) * (P + 1)).astype(np.int32), rng.gamma(0.03, 1.0, size=(mt + 2) * O), rng.rand(mt + 2))
@@ -68,14 +73,18 @@ def test_random_configuration_against_the_oracle(seed):
     eng.selfplay_start()
     while eng.selfplay_select() > 0:
         planes, _ = eng.leaf_batch()
-        eng.selfplay_finish(*fake_eval_planes(planes, O))
+        pri, v = fake_eval_planes(planes, O)
+        if f64:   # the same hash evaluator handing out float64: every N / W / P intermediate is then a double
+            pri, v = pri.astype(np.float64), v.astype(np.float64)
+        eng.selfplay_finish(pri, v)
     ctr = eng.counters()
     page = ctr["tree_page_edges"]
     held = sum(max(1, -(-eng.tree_size(s, side)[0] // page)) for s in range(G) for side in (0, 1))
     assert ctr["tree_pool_pages_in_use"] == held, (c, ctr)
     assert ctr["expansions_skipped"] == 0
     for s in range(G):
-        ref = oz.play_game(game, H, H, k, tt, P, db, mt, oz.fn_ptr("oz_fake_eval"), oz.Rng(*streams[s]))
+        ref = oz.play_game(game, H, H, k, tt, P, db, mt, oz.fn_ptr("oz_fake_eval", real64=f64), oz.Rng(*streams[s]), real64=f64,
+                           K=K, vloss=vloss)
         tr = eng.trajectory_pop(s)
         assert np.array_equal(tr["moves"], ref["moves"]), (c, s)
         assert np.array_equal(tr["visits"], ref["visits"]), (c, s)
