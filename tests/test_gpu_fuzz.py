@@ -1,6 +1,7 @@
 """GPU parity on randomly drawn configurations: game, board, simulation count, noise horizon, game length, slot count,
 page size and size of the shared edge pool, tree limits with the growing policy, leaves per round (the virtual-loss
-schedule, defined by the oracle's oz_tree_search_k), float32 or float64 search statistics - whole games of the HIP engine against
+schedule, defined by the oracle's oz_tree_search_k), float32 or float64 search statistics, one evaluator or two with a
+random assignment of who moves first (the gating matches) - whole games of the HIP engine against
 the C oracle's oz_play_game, visit for visit.  The fixed cases of the other test files pin known shapes; this one walks
 the space between them (children straddling pages, trees emptied and refilled by re-roots, pools that run dry and grow).
 
@@ -17,6 +18,7 @@ pytestmark = pytest.mark.gpu
 
 N = int(os.environ.get("AZ_FUZZ_N", "16"))
 SEED0 = int(os.environ.get("AZ_FUZZ_SEED", "0"))
+SALTS = (5, 99)   # the two hash "networks" of a two-evaluator game
 
 
 def draw(seed):
@@ -53,7 +55,9 @@ def draw(seed):
     K = int(r.choice([1, 1, 1, 2, 3, 5, 8]))
     vloss = float(r.choice([0.25, 1.0]))
     f64 = bool(r.rand() < 0.2)
-    return dict(game=game, H=H, k=k, P=P, tt=tt, db=db, mt=mt, G=G, O=O, kw=kw, K=K, vloss=vloss, f64=f64)
+    match = bool(K == 1 and not f64 and r.rand() < 0.3)   # two evaluators: Game(ev_a, ev_b) or the two swapped, per slot
+    first = r.randint(0, 2, size=G).astype(np.int32)
+    return dict(game=game, H=H, k=k, P=P, tt=tt, db=db, mt=mt, G=G, O=O, kw=kw, K=K, vloss=vloss, f64=f64, match=match, first=first)
 
 
 @pytest.mark.parametrize("seed", range(SEED0, SEED0 + N))
@@ -71,9 +75,18 @@ def test_random_configuration_against_the_oracle(seed):
         streams.append(st)
         eng.rng_inject(s, *st)
     eng.selfplay_start()
+    if c["match"]:
+        eng.match_assign(np.arange(G), c["first"])
     while eng.selfplay_select() > 0:
         planes, _ = eng.leaf_batch()
         pri, v = fake_eval_planes(planes, O)
+        if c["match"]:   # the engine says which network owns each leaf; rows that need no answer get one that would show if read
+            nets = eng.match_leaf_nets()
+            pri[:], v[:] = np.nan, np.nan
+            for net in (0, 1):
+                rows = np.flatnonzero(nets == net)
+                if rows.size:
+                    pri[rows], v[rows] = fake_eval_planes(planes[rows], O, SALTS[net])
         if f64:   # the same hash evaluator handing out float64: every N / W / P intermediate is then a double
             pri, v = pri.astype(np.float64), v.astype(np.float64)
         eng.selfplay_finish(pri, v)
@@ -83,8 +96,9 @@ def test_random_configuration_against_the_oracle(seed):
     assert ctr["tree_pool_pages_in_use"] == held, (c, ctr)
     assert ctr["expansions_skipped"] == 0
     for s in range(G):
+        salts = (SALTS[c["first"][s]], SALTS[1 - c["first"][s]]) if c["match"] else None
         ref = oz.play_game(game, H, H, k, tt, P, db, mt, oz.fn_ptr("oz_fake_eval", real64=f64), oz.Rng(*streams[s]), real64=f64,
-                           K=K, vloss=vloss)
+                           K=K, vloss=vloss, salts=salts)
         tr = eng.trajectory_pop(s)
         assert np.array_equal(tr["moves"], ref["moves"]), (c, s)
         assert np.array_equal(tr["visits"], ref["visits"]), (c, s)
