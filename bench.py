@@ -191,6 +191,52 @@ def hbm_kernels(c, cells, O, steps, peak_gbs=8000.0):
     return out
 
 
+class PostRegionGuard:
+    """The measured line is complete when the timed region ends; the exercises that run after it (exchanges between ranks,
+    parity check, other tower format, CPU baseline) only add blocks to it.  None of them may cost the measurement: if they
+    have not finished after `seconds` (a collective that never completes on some fabric), rank 0 prints the line as it
+    stands, saying so in `post_region_note`, and the process leaves - every rank runs its own guard, so all of them do."""
+
+    def __init__(self, out, rank, seconds, emit=None, leave=os._exit):
+        import threading
+        self.out, self.rank, self.seconds = out, rank, seconds
+        self._emit_fn = emit if emit is not None else _emit
+        self._leave = leave
+        self._lock = threading.Lock()
+        self.emitted = False
+        self._timer = threading.Timer(seconds, self._expired)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def emit(self, note=None):
+        with self._lock:
+            if self.emitted:
+                return
+            self.emitted = True
+            if self.rank == 0:
+                if note:
+                    self.out["post_region_note"] = note
+                self._emit_fn(json.dumps(self.out))
+
+    def _expired(self):
+        self.emit("the work after the timed region did not finish within %.0f s and was abandoned" % self.seconds)
+        self._leave(0)
+
+    def record(self, key, fn):
+        """Runs one exercise; its result (or the error it raised) becomes out[key] unless the line has gone out already."""
+        try:
+            val = fn()
+        except Exception as e:  # noqa: BLE001 - a failed exercise is reported in its place
+            val = {"error": "%s: %s" % (type(e).__name__, e)}
+        if self.rank == 0:
+            with self._lock:
+                if not self.emitted:
+                    self.out[key] = val
+
+    def done(self):
+        self._timer.cancel()
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -553,37 +599,8 @@ def main(args):
     # ---- after the timed region: the exchanges of a multi-GPU job, the tower's 16-bit error on this run's boards, the CPU
     # baseline.  None of it may cost the measurement: if it has not finished after --post-timeout seconds (a collective that
     # never completes on some fabric), rank 0 prints the line as it stands, saying so, and every rank leaves.
-    import threading
-    lock = threading.Lock()
-    state = {"emitted": False}
-
-    def emit_once(note=None):
-        with lock:
-            if state["emitted"]:
-                return
-            state["emitted"] = True
-            if rank == 0:
-                if note:
-                    out["post_region_note"] = note
-                _emit(json.dumps(out))
-
-    def expired():
-        emit_once("the work after the timed region did not finish within %.0f s and was abandoned" % args.post_timeout)
-        os._exit(0)
-
-    timer = threading.Timer(args.post_timeout, expired)
-    timer.daemon = True
-    timer.start()
-
-    def record(key, fn):
-        try:
-            val = fn()
-        except Exception as e:  # noqa: BLE001 - a failed exercise is reported in its place
-            val = {"error": "%s: %s" % (type(e).__name__, e)}
-        if rank == 0:
-            with lock:
-                if not state["emitted"]:
-                    out[key] = val
+    guard = PostRegionGuard(out, rank, args.post_timeout)
+    record = guard.record
 
     if not args.no_exchange:
         record("exchange", lambda: exchange_exercise(eng, parallel, torch, dist, rank, world, dev, blob_t, O,
@@ -599,12 +616,12 @@ def main(args):
         record("other_16bit_format", lambda: other_16bit_format(args, Engine, fold_to_blob, random_net, H, O, local_rank, rps))
     if rank == 0 and not args.no_cpu_baseline and world == 1:  # reported at N=1 only; at N>1 the other ranks would idle behind it
         record("cpu_baseline", lambda: cpu_baseline(args.game, H, args.k, args.blocks, args.channels, args.sims))
-    emit_once()
+    guard.emit()
     eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    timer.cancel()
+    guard.done()
 
 
 # The one JSON line must be the only thing on stdout, but libraries write there too (RCCL prints a version banner when

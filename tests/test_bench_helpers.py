@@ -112,3 +112,45 @@ def test_telemetry_is_off_under_a_profiler(monkeypatch):
     assert not bench.PowerSampler.under_profiler()
     monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
     assert bench.PowerSampler.under_profiler()
+
+
+def test_post_region_guard_prints_the_line_once_with_whatever_finished():
+    import json
+    lines = []
+    out = {"value": 1.5, "exchange": None}
+    g = bench.PostRegionGuard(out, 0, 30.0, emit=lines.append, leave=lambda code: None)
+    g.record("exchange", lambda: {"ok": True})
+    g.record("tower_parity", lambda: 1 / 0)          # a failing exercise is reported in its place
+    g.emit()
+    g.emit()
+    g.done()
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] == 1.5 and d["exchange"] == {"ok": True} and "ZeroDivisionError" in d["tower_parity"]["error"]
+    assert "post_region_note" not in d
+
+
+def test_post_region_guard_abandons_a_hanging_exercise():
+    """An exercise that never returns (a collective that hangs) may not cost the measurement: after the deadline the
+    line goes out as it stands and the process is told to leave; what the hung exercise returns later is ignored."""
+    import json
+    import threading
+    lines, left = [], threading.Event()
+    out = {"value": 2.5, "exchange": None}
+    g = bench.PostRegionGuard(out, 0, 0.2, emit=lines.append, leave=lambda code: left.set())
+    release = threading.Event()
+    g.record("exchange", lambda: (release.wait(5.0), {"late": True})[1])   # blocks past the deadline
+    assert left.wait(5.0)
+    release.set()
+    g.emit()
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] == 2.5 and d["exchange"] is None and "did not finish" in d["post_region_note"]
+
+
+def test_post_region_guard_is_silent_on_other_ranks():
+    lines, left = [], []
+    g = bench.PostRegionGuard(None, 3, 0.05, emit=lines.append, leave=left.append)
+    import time
+    time.sleep(0.3)
+    assert lines == [] and left == [0]
