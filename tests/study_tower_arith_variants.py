@@ -2,7 +2,7 @@
 """CPU model of the 16-bit tower's arithmetic in several variants, each against the float64 value of the network formula
 (oracle/tower_ref.forward): which rounding costs what at the depths the configurations name.  Runs without a GPU.
 
-    python tools/tower_arith_variants.py <board> <blocks> <seeds>
+    python tests/study_tower_arith_variants.py <board> <blocks> <seeds>
 
 Variants: the device's bf16 arithmetic (conv output rounded to bf16 before the residual is added, then again after), one
 rounding per layer, a float32 residual stream, float32 heads, float32 weights with bf16 activations, and the same with

@@ -1,5 +1,6 @@
-"""Error budget of the bf16 tower at depth (GPU): HIP bf16 / fp32 outputs against the fp32 and float64 evaluations of
-the network restatement and against a CPU model of the bf16 arithmetic.  Prints one line per case."""
+"""Error budget of the towers at depth (GPU; a study script, not collected by pytest): HIP bf16 / f16 / fp32 outputs against the
+fp32 and float64 evaluations of the network restatement and against a CPU model of the bf16 arithmetic.  One line per case.
+    python tests/study_tower_depth_errors.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -23,7 +24,7 @@ for game, H, NB, B in [("go", 19, 20, 2), ("go", 19, 20, 96), ("go", 9, 10, 410)
         r32 = tower_ref.forward(net.state_dict(), xt, NB)
         r64 = tower_ref.forward(net.state_dict(), xt, NB, dtype=torch.float64)
         rbf = tower_ref.forward_bf16_model(blob, xt, H, H, O, NB, 256)
-        for dt in ("bf16", "fp32"):
+        for dt in ("bf16", "f16", "fp32"):
             eng = Engine(game, H, H, n_slots=max(B, 4), num_blocks=NB, channels=256, tower_dtype=dt)
             eng.tower_load(blob)
             p, v = eng.tower_forward(x)

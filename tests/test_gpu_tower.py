@@ -205,7 +205,7 @@ def _deep_net(H, O, NB, seed):
 #   1e-2 already at 6 blocks (8e-3 on the three boards of the first test below, 1.2e-2 on boards of the full-tile test) and
 #   1e-2 ... 4e-2 away at 10 and 20 blocks, for any bf16 implementation: a CPU model of the same
 #   arithmetic (oracle/tower_ref.forward_bf16_model) is as far from the float64 value as the HIP tower, and no variant of
-#   the arithmetic that keeps bf16 operands on the matrix cores gets closer (tools/tower_arith_variants.py).  Those cases
+#   the arithmetic that keeps bf16 operands on the matrix cores gets closer (tests/study_tower_arith_variants.py).  Those cases
 #   carry "value_widened" in their id and are held to 1e-2 + 3 x the CPU model's own distance on the same boards (never
 #   more than 1e-1): the kernels may not add to what the number format costs.
 LITERAL, WIDENED = "literal_1e-2", "value_widened_to_bf16_model"
