@@ -91,6 +91,7 @@ SIGNATURES = {
     "az_search_advance": (_I, [_P, _P, _I, _P]),
     "az_search_tree_size": (_I, [_P, _I, _I, _P, _P]),
     "az_search_grow_trees": (_I, [_P, _I, _I]),
+    "az_search_grow_pool": (_I, [_P, C.c_int64]),
     "az_search_set_c_punt": (_I, [_P, C.c_double]),
     "az_selfplay_start": (_I, [_P]),
     "az_selfplay_run": (_I, [_P, _I]),

@@ -246,6 +246,16 @@ extern "C" int az_search_grow_trees(az_engine *h, int32_t edge_cap, int32_t bloc
     return grow_trees(h, ec, block_cap ? block_cap : 2LL * h->D.BC, pages);
 }
 
+extern "C" int az_search_grow_pool(az_engine *h, int64_t pool_edges)
+{
+    if (!h || pool_edges < 0) return AZ_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const long long page = 1LL << h->D.PS, most = 2LL * h->D.G * h->D.PTC;
+    long long pages = pool_edges ? (pool_edges + page - 1) / page : 2LL * h->D.pool_pages;
+    if (pages > most) pages = most;
+    return grow_trees(h, h->D.EC, h->D.BC, pages);
+}
+
 extern "C" const char *az_last_error(az_engine *h) { return h ? h->error.c_str() : g_create_error.c_str(); }
 
 extern "C" void az_engine_destroy(az_engine *h)

@@ -220,6 +220,10 @@ class Engine:
         """Raise every tree's limits (0 = double) and the shared edge pool with them; contents are kept."""
         self._ck(self._L.az_search_grow_trees(self._h, int(edge_cap), int(block_cap)))
 
+    def grow_pool(self, pool_edges=0):
+        """Enlarge only the shared pool of tree edges (0 = double, never beyond every tree at its limit); trees are kept."""
+        self._ck(self._L.az_search_grow_pool(self._h, int(pool_edges)))
+
     def set_c_punt(self, c_punt):
         """Assigning the module global c_punt of the reference's search module (search/mcts.py:9): used from the next
         selection step on."""

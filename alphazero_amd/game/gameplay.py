@@ -122,9 +122,11 @@ class BatchedSelfplay:
     """`n_games` concurrent self-play games on one GPU; the role of Selfplay.run +
     selfplay_wrapper (train/parallel/selfplay.py:71-108) without a process per game.
 
-    The engine runs with tree_full_policy 1: should a search tree ever outgrow its arena (long forced lines with
+    The engine runs with tree_full_policy 1: should a search tree ever outgrow its limit (long forced lines with
     almost all visits kept across re-roots), that playout's node stays a leaf instead of stopping every game;
-    `eng.counters()["expansions_skipped"]` tells how often that happened (0 = the run is exact).
+    `eng.counters()["expansions_skipped"]` tells how often that happened (0 = the run is exact).  The pool of edge
+    pages all trees share starts at half of what every tree at its limit would need and is doubled between polls
+    whenever more than POOL_GROW_AT of it has been in use, so a page is never what an expansion lacks.
 
     Finished games are turned into get_history() tuples on a second engine (its own HIP stream) by a
     background thread, so the self-play engine keeps running rounds meanwhile.
@@ -139,15 +141,18 @@ class BatchedSelfplay:
     draws instead of using its own generator (parity tests)."""
 
     REPLAY_SLOTS = 64
+    POOL_GROW_AT = 0.8
 
-    def __init__(self, nn_eval, game_config, ext_config, n_games, seed=0, device=0, update="immediate", rng_streams=None):
+    def __init__(self, nn_eval, game_config, ext_config, n_games, seed=0, device=0, update="immediate", rng_streams=None,
+                 tree_pool_edges=0):
         if update not in ("immediate", "drain"):
             raise ValueError("update must be 'immediate' or 'drain'")
         kw = game_config_to_engine_kwargs(game_config)
         self.eng = Engine(n_slots=n_games, max_playout=ext_config['player']['max_playout'],
                           dirichlet_before=ext_config['dirichlet_before'], max_turn=ext_config['max_turn'],
                           record_trajectories=True, seed=seed, num_blocks=nn_eval.num_blocks, channels=nn_eval.channels,
-                          tower_dtype=nn_eval.dtype, device=device, tree_full_policy=1, rng_replay=rng_streams is not None, **kw)
+                          tower_dtype=nn_eval.dtype, device=device, tree_full_policy=1, rng_replay=rng_streams is not None,
+                          tree_pool_edges=tree_pool_edges, **kw)
         if rng_streams is not None:
             if len(rng_streams) != n_games:
                 raise ValueError("one (tids, etas, unis) triple per slot")
@@ -175,6 +180,13 @@ class BatchedSelfplay:
             out += history_arrays_batch(self._replay, popped[i:i + self.REPLAY_SLOTS])
         return out
 
+    def _watch_pool(self):
+        c = self.eng.counters()
+        if c["tree_pool_pages_peak"] > self.POOL_GROW_AT * c["tree_pool_pages"]:
+            most = 2 * self.n_games * -(-c["tree_edge_cap"] // c["tree_page_edges"])
+            if c["tree_pool_pages"] < most:
+                self.eng.grow_pool()
+
     def _weights_between_polls(self):
         if self._version == self._nn_eval.version:
             return
@@ -198,6 +210,7 @@ class BatchedSelfplay:
             while len(slots) < num_games:
                 self.eng.selfplay_run(rounds_per_poll)    # the C call releases the GIL: the worker converts meanwhile
                 plies, done = self.eng.selfplay_status()
+                self._watch_pool()
                 fin = np.flatnonzero((done != 0) & ~self._empty)
                 popped = [(tr["moves"], tr["visits"], tr["winner"])
                           for tr in self.eng.trajectory_pop_many(fin, plies[fin], restart=not self._draining)]

@@ -224,6 +224,12 @@ int az_search_advance(az_engine *h, const int32_t *slots, int32_t n, const int32
  * shrinks) and enlarge the shared edge pool by the same factor as edge_cap; the trees keep their contents.  What
  * tree_full_policy 2 does by itself. */
 int az_search_grow_trees(az_engine *h, int32_t edge_cap, int32_t block_cap);
+/* Enlarge only the shared edge pool, to pool_edges edges (0 = twice the present size; never shrinks, and never beyond what all
+ * trees at their limit would need); limits and trees stay as they are.  A production driver calls it between rounds when
+ * az_counters.tree_pool_pages_peak comes close to tree_pool_pages, so that no expansion is ever skipped for want of a page
+ * (tree_full_policy 1) without sizing the pool for the worst case up front.  No counterpart in the reference, whose tree is an
+ * unbounded heap (search/mcts.py:30-52). */
+int az_search_grow_pool(az_engine *h, int64_t pool_edges);
 /* nodes (edges) and expanded nodes currently held by a tree */
 int az_search_tree_size(az_engine *h, int32_t slot, int32_t side, int32_t *edges, int32_t *blocks);
 /* Assigning the module global c_punt of search/mcts.py:9: the value every later selection step uses (c_punt > 0). */

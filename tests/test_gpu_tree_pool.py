@@ -164,3 +164,68 @@ def test_bad_page_size_is_refused():
     for page in (100, 64):   # not a power of two; smaller than the 82 actions of a 9x9 board
         with pytest.raises(EngineError):
             Engine("go", 9, 9, n_slots=1, max_playout=8, tree_page_edges=page)
+
+
+def test_growing_only_the_pool_keeps_limits_and_trees():
+    from alphazero_amd.engine import Engine
+    eng = Engine("go", 9, 9, n_slots=2, max_playout=100, transform_types=8, tree_page_edges=128, tree_pool_edges=6 * 128, seed=4)
+    eng.search_begin([0, 1], [0, 0], [0, 1])
+    for _ in range(3):
+        assert eng.step_select() > 0
+        planes, _ = eng.leaf_batch()
+        eng.step_finish(*fake_eval_planes(planes, eng.O))
+    before = [eng.root_stats(s, 0) for s in (0, 1)]
+    c0 = eng.counters()
+    assert c0["tree_pool_pages"] == 6
+    eng.grow_pool()
+    c1 = eng.counters()
+    assert c1["tree_pool_pages"] == 12 and c1["tree_edge_cap"] == c0["tree_edge_cap"] and c1["tree_block_cap"] == c0["tree_block_cap"]
+    assert c1["tree_pool_pages_in_use"] == c0["tree_pool_pages_in_use"] == _pages_held(eng)
+    eng.grow_pool(10 ** 12)   # never beyond every tree at its limit
+    most = 4 * -(-c0["tree_edge_cap"] // 128)
+    assert eng.counters()["tree_pool_pages"] == most
+    eng.grow_pool()           # already there: nothing to do
+    assert eng.counters()["tree_pool_pages"] == most
+    for s in (0, 1):
+        for x, y in zip(before[s], eng.root_stats(s, 0)):
+            assert np.array_equal(x, y)
+    while eng.step_select() > 0:
+        planes, _ = eng.leaf_batch()
+        eng.step_finish(*fake_eval_planes(planes, eng.O))
+    for s in (0, 1):
+        a, n, w, p, rootN = eng.root_stats(s, 0)
+        assert rootN == 101 and n.sum() == 100
+    eng.close()
+
+
+def test_batched_selfplay_grows_its_pool_before_a_page_is_missed():
+    """BatchedSelfplay starts with whatever pool it is given and doubles it between polls once a set share of it (80 %; 40 %
+    here) has been in use: with a pool of one page per tree and a poll after every round, whole games come out the same as with an ample pool and no
+    expansion is skipped."""
+    import yaml
+    import os
+    from alphazero_amd.evaluator.nn_eval import NNEvaluator
+    from alphazero_amd.game.gameplay import BatchedSelfplay
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "alphazero_amd", "config", "go.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    H, P, G, mt = 7, 40, 4, 30
+    O = H * H + 1
+    cfg.update(board_height=H, board_width=H, flat_move_output=O, transform_types=8)
+    ev = NNEvaluator(cfg, num_blocks=1, channels=128, dtype="fp32", max_batch_size=1)
+    ext = {"player": {"max_playout": P}, "dirichlet_before": 6, "max_turn": mt}
+    streams = _streams(np.random.RandomState(9), G, mt, P, O)
+    out = []
+    for pool in (2 * G * 64, 0):
+        sp = BatchedSelfplay(ev, cfg, ext, n_games=G, rng_streams=streams, tree_pool_edges=pool)
+        pages0 = sp.eng.counters()["tree_pool_pages"]
+        sp.POOL_GROW_AT = 0.4    # (four trees search in step and may each want a page in one round: keep more than that free)
+        hist = sp.run(G, rounds_per_poll=1)
+        c = sp.eng.counters()
+        assert c["expansions_skipped"] == 0
+        if pool:
+            assert pages0 == 2 * G and c["tree_pool_pages"] > pages0
+        out.append([hist[sp.last_slots.index(s)] for s in range(G)])
+        sp.eng.close()
+    for a, b in zip(*out):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
