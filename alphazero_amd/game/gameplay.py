@@ -118,6 +118,19 @@ class Game:
         return state_np, probs_np, outcome_labels(T, self.winner, self._black)
 
 
+def grow_pool_when_used(eng, share=0.8):
+    """Doubles the engine's shared pool of tree-edge pages once more than `share` of it has been in use at some moment
+    (and every tree at its limit would need more than it holds): called between polls by the batched drivers, so that an
+    expansion never lacks a page although the pool is not sized for the worst case up front."""
+    c = eng.counters()
+    if c["tree_pool_pages_peak"] > share * c["tree_pool_pages"]:
+        most = 2 * eng.G * -(-c["tree_edge_cap"] // c["tree_page_edges"])
+        if c["tree_pool_pages"] < most:
+            eng.grow_pool()
+            return True
+    return False
+
+
 class BatchedSelfplay:
     """`n_games` concurrent self-play games on one GPU; the role of Selfplay.run +
     selfplay_wrapper (train/parallel/selfplay.py:71-108) without a process per game.
@@ -181,11 +194,7 @@ class BatchedSelfplay:
         return out
 
     def _watch_pool(self):
-        c = self.eng.counters()
-        if c["tree_pool_pages_peak"] > self.POOL_GROW_AT * c["tree_pool_pages"]:
-            most = 2 * self.n_games * -(-c["tree_edge_cap"] // c["tree_page_edges"])
-            if c["tree_pool_pages"] < most:
-                self.eng.grow_pool()
+        grow_pool_when_used(self.eng, self.POOL_GROW_AT)
 
     def _weights_between_polls(self):
         if self._version == self._nn_eval.version:
@@ -289,6 +298,7 @@ class BatchedMatch:
         while finished < self.num_games:
             eng.selfplay_run(rounds_per_poll)
             plies, done = eng.selfplay_status()
+            grow_pool_when_used(eng)
             fin = [int(s) for s in np.flatnonzero(done) if game_of_slot[int(s)] is not None]
             n_more = min(len(fin), self.num_games - next_game)
             again, last = fin[:n_more], fin[n_more:]      # slots that take another game / that stay empty
