@@ -18,6 +18,7 @@ for it in range(40):
     e.tower_profile(8)                                   # sampled per-launch timing: the tower's event pool
     e.selfplay_run(20)
     pl, dn = e.selfplay_status()
+    e.grow_trees(); e.grow_pool()                        # limits, page tables and the edge pool re-allocated
     e.rng_inject(0, [1, 2, 3], [0.5], [0.1])
     e.close()
     free, tot = torch.cuda.mem_get_info(0)
