@@ -29,7 +29,7 @@ def _games(rank, O, shapes, max_count):
     return out
 
 
-SHAPES = {0: [401, 3, 0, 250], 1: [77, 401, 401]}      # ragged, up to max_turn + 1 = 401 plies of Go 19x19
+SHAPES = {0: [401, 3, 0, 250], 1: [77, 401, 401], 2: [], 3: [12, 401]}      # ragged, up to max_turn + 1 = 401 plies of Go 19x19
 
 
 class _StubEngine:
@@ -97,23 +97,31 @@ def _work(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_broadcast_and_gather_world2():
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_broadcast_and_gather(world):
+    """world 2, and world 4 with a rank that has nothing to send: rank 0 takes the ranks' blobs one after the other while
+    the others wait their turn."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in ps:
         p.start()
-    res = dict(q.get(timeout=180) for _ in range(2))
+    res = dict(q.get(timeout=180) for _ in range(world))
     for p in ps:
         p.join(timeout=60)
-    for rank in (0, 1):
+    total = sum(len(SHAPES[r]) for r in range(world))
+    for rank in range(world):
         r = res[rank]
         assert "error" not in r, r["error"]
         assert r["weights"] and r["gather"] and r["wide"] and r["update"] and r["empty"] == 0, (rank, r)
         assert r["wire_dtype"] == "torch.uint8"
-        assert r["n_got"] == (7 if rank == 0 else 0)          # only rank 0, the replay buffer's home, receives
-        assert r["ratio"] < 0.25                              # packed rows against dense int32 rows
+        assert r["n_got"] == (total if rank == 0 else 0)      # only rank 0, the replay buffer's home, receives
+        if SHAPES[rank]:
+            assert r["ratio"] < 0.25                          # packed rows against dense int32 rows
 
 
 def test_pack_roundtrip_and_sharding():
