@@ -63,3 +63,31 @@ def test_go19_run_is_reproducible_from_the_seed():
         assert np.array_equal(x["moves"], y["moves"]) and np.array_equal(x["visits"], y["visits"]) and x["winner"] == y["winner"]
     other = _run(10)
     assert any(not np.array_equal(x["moves"], y["moves"]) for x, y in zip(a[2], other[2]))
+
+
+def test_edge_pool_accounting_at_the_bench_size():
+    """3993 games of Go 19x19 at 800 simulations with the bench's pool (a third of one arena per tree): after a few hundred
+    rounds, and again after every game has moved and both of its trees were re-rooted, every page in use belongs to exactly
+    one tree and nothing was skipped."""
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.network.model import fold_to_blob, random_net
+    Gb, O = 3993, H * H + 1
+    eng = Engine("go", H, H, n_slots=Gb, max_playout=P, transform_types=8, dirichlet_before=30, max_turn=400, seed=3,
+                 num_blocks=1, channels=128, tower_dtype="bf16", tree_pool_edges=2 * Gb * (P + 1) * O)
+    eng.tower_load(fold_to_blob(random_net(H, H, O, 1, 128, seed=1)))
+    eng.selfplay_start()
+
+    def held():
+        page = eng.counters()["tree_page_edges"]
+        return sum(max(1, -(-eng.tree_size(s, side)[0] // page)) for s in range(Gb) for side in (0, 1))
+
+    eng.selfplay_run(300)
+    c = eng.counters()
+    assert c["tree_pool_pages_in_use"] == held() and c["expansions_skipped"] == 0
+    assert c["tree_pool_pages_in_use"] > 2 * Gb                      # the searching trees have taken pages beyond their own
+    eng.selfplay_run(P + 1 - 300 + 2)                                 # every game finishes its search, moves, re-roots
+    c = eng.counters()
+    assert c["moves"] == Gb and c["expansions_skipped"] == 0
+    assert c["tree_pool_pages_in_use"] == held()
+    assert c["tree_pool_pages_in_use"] < c["tree_pool_pages_peak"] <= c["tree_pool_pages"]   # the re-roots gave pages back
+    eng.close()
