@@ -86,7 +86,7 @@ class MCTSearch(object):
             raise ValueError("leaves_per_round > 1 needs a device evaluator (NNEvaluator)")
         # replayed draws follow the reference's sequential order, which several leaves in flight do not have
         # the reference's tree has no size limit and a re-rooted tree keeps the chosen child's subtree (a sharply peaked
-        # policy keeps most of it, ply after ply): the arenas double whenever one fills up (tree_full_policy 2)
+        # policy keeps most of it, ply after ply): the trees' limits and the edge pool double whenever one runs out (tree_full_policy 2)
         self._eng_kw = dict(n_slots=1, max_playout=max_playout, rng_replay=leaves_per_round <= 1,
                             leaves_per_round=leaves_per_round, tree_full_policy=2, **kw)
         self._multi = leaves_per_round > 1

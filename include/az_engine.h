@@ -79,11 +79,12 @@ typedef struct az_config {
                                   (single-game / play use: K times the evaluator batch); per-leaf arrays then have
                                   K * n_slots rows, row j * n_slots + slot for the j-th leaf of a slot */
     double virtual_loss;       /* K > 1: subtracted from W of every edge on a path in flight, given back when its value arrives */
-    int32_t tree_full_policy;  /* 0: a full tree arena stops the run with AZ_ERR_TREE_FULL (the reference has no limit, so
+    int32_t tree_full_policy;  /* what happens when a tree reaches tree_edge_cap / tree_block_cap or the shared edge pool has no
+                                  page left.  0: the run stops with AZ_ERR_TREE_FULL (the reference has no limit, so
                                   nothing else is exact); 1: the node stays a leaf for that playout, its value is still
                                   backed up, and az_counters.expansions_skipped counts the event (production runs);
-                                  2: the arenas of all trees are doubled and the stopped playout is completed when the
-                                  call that ran the round returns - exact like 0, without the limit (single games) */
+                                  2: the limits of all trees and the pool are doubled and the stopped playout is completed
+                                  when the call that ran the round returns - exact like 0, without the limit (single games) */
     int32_t search_f64;        /* 0: N/W/P arithmetic in float32 (a float32 evaluator: the network, nn_eval_parallel.py:75-92);
                                   1: in float64 (an evaluator returning Python floats / float64: evaluator/dummy_eval.py:26-28).
                                   With 1 the tower cannot feed the search; use the *_f64 entry points */
@@ -142,10 +143,10 @@ typedef struct az_counters {
     double conv_ms;            /* HIP-event time of the residual-tower 3x3 conv launches (az_tower_profile on) */
     uint64_t conv_launches;
     double conv_flops_per_launch; /* mean over the timed launches of 2 * boards in the launch * H*W * 9 * C^2 */
-    uint64_t expansions_skipped;  /* tree_full_policy 1: expansions dropped because an arena was full */
+    uint64_t expansions_skipped;  /* tree_full_policy 1: expansions dropped because a tree was at its limit or the pool empty */
     uint64_t peak_tree_edges;     /* most edges / expanded nodes any one tree has held since the last reset ... */
     uint64_t peak_tree_blocks;
-    uint64_t tree_edge_cap;       /* ... against the arena sizes in force (az_config.tree_edge_cap / tree_block_cap) */
+    uint64_t tree_edge_cap;       /* ... against the per-tree limits in force (az_config.tree_edge_cap / tree_block_cap) */
     uint64_t tree_block_cap;
     uint64_t tree_page_edges;     /* the shared pool of tree edges: edges per page, */
     uint64_t tree_pool_pages;     /* pages in the pool, */
