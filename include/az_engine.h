@@ -117,7 +117,7 @@ typedef struct az_config {
     int32_t reserved0;         /* 0 */
 } az_config;
 
-/* Fixed-layout copy of one game state (attributes of env/*.py GameState). */
+/* Fixed-layout copy of one game state (attributes of the GameState classes of env/go.py, env/reversi.py, env/mnk.py). */
 typedef struct az_state_blob {
     int8_t board[AZ_CELL_PAD];
     int8_t history[7][AZ_CELL_PAD];   /* board_history, oldest first */
