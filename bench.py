@@ -288,12 +288,34 @@ def launch_ranks(args, argv, script=None):
     port = s.getsockname()[1]
     s.close()
     procs = []
+
+    def die_with_parent():
+        # (runs in the child between fork and exec) a rank must not outlive a launcher that was killed: it would keep its GPU
+        try:
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, 9)   # PR_SET_PDEATHSIG, SIGKILL
+        except Exception:  # noqa: BLE001 - not Linux / no libc: the signal handlers below still cover an orderly end
+            pass
+
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=None if r == 0 else sys.stderr))
+                                      stdout=None if r == 0 else sys.stderr, preexec_fn=die_with_parent))
+
+    def ended(signum, frame):   # the launcher is told to stop: so are its ranks
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        sys.exit(128 + signum)
+
+    import signal
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        try:
+            signal.signal(sig, ended)
+        except ValueError:      # not the main thread (tests call this function directly)
+            pass
     status = 0
     live = set(range(n))
     while live:

@@ -154,3 +154,45 @@ def test_post_region_guard_is_silent_on_other_ranks():
     import time
     time.sleep(0.3)
     assert lines == [] and left == [0]
+
+
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except OSError:
+        return False
+    try:    # a zombie that nobody has reaped yet is not running any more
+        with open("/proc/%d/stat" % pid) as f:
+            return f.read().split(")")[-1].split()[0] != "Z"
+    except OSError:
+        return False
+
+
+def test_ranks_do_not_outlive_a_launcher_that_is_stopped_or_killed(tmp_path):
+    """SIGTERM: the launcher ends its ranks.  SIGKILL (no handler can run): the ranks were started with a parent-death
+    signal and go with it - a rank left behind would keep its GPU from the next run."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    stub = tmp_path / "sleeper.py"
+    stub.write_text("import os, sys, time\nopen(os.path.join(%r, 'pid_' + os.environ['RANK']), 'w').write(str(os.getpid()))\ntime.sleep(120)\n" % str(tmp_path))
+    code = ("import importlib.util, sys; spec = importlib.util.spec_from_file_location('bench', %r); b = importlib.util.module_from_spec(spec); "
+            "spec.loader.exec_module(b); a = b.parse_args(['--gpus', '2']); sys.exit(b.launch_ranks(a, ['--gpus', '2'], script=%r))"
+            % (os.path.join(ROOT, "bench.py"), str(stub)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        for f in tmp_path.glob("pid_*"):
+            f.unlink()
+        p = subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        t0 = time.time()
+        while len(list(tmp_path.glob("pid_*"))) < 2 and time.time() - t0 < 60:
+            time.sleep(0.1)
+        pids = [int(f.read_text()) for f in tmp_path.glob("pid_*")]
+        assert len(pids) == 2 and all(_alive(x) for x in pids)
+        p.send_signal(sig)
+        p.wait(timeout=30)
+        t0 = time.time()
+        while any(_alive(x) for x in pids) and time.time() - t0 < 20:
+            time.sleep(0.1)
+        assert not any(_alive(x) for x in pids), sig
